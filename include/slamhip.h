@@ -1,0 +1,194 @@
+/*
+ * slamhip.h - C ABI of libslamhip.so, the MI355X (gfx950) implementation of the
+ * stereo-SLAM front-end hot path: Hamming brute-force kNN descriptor matching,
+ * rectified-stereo row/disparity filter, 4x4 DLT triangulation and PnP-RANSAC
+ * hypothesis consensus scoring.
+ *
+ * Conventions
+ *  - Every pointer named d_* is a DEVICE pointer (hipMalloc / torch ROCm tensor
+ *    data_ptr()).  Small parameter blocks (camera matrices) are HOST pointers and
+ *    are copied by value into the kernel arguments.
+ *  - The caller owns every buffer.  The library allocates no device memory;
+ *    kernels that need scratch take a caller-provided workspace whose size is
+ *    returned by the matching *_workspace_bytes() function.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  All
+ *    calls are asynchronous on that stream and return after enqueueing.
+ *  - Return value: SLAMHIP_OK (0) or a negative SLAMHIP_E* code.  Nothing throws
+ *    across this boundary.  slamhip_strerror() maps a code to text.
+ *  - Thread-safety: no global mutable state; calls on different streams/devices
+ *    may run concurrently.
+ *
+ * Each entry point cites the reference interface (GuyShmueli/SLAM, paths
+ * relative to the reference root) whose arithmetic it replaces.
+ */
+#ifndef SLAMHIP_H
+#define SLAMHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SLAMHIP_VERSION 100 /* 0.1.0 */
+
+enum {
+  SLAMHIP_OK = 0,
+  SLAMHIP_EINVAL = -1,      /* null pointer / negative size / bad flag          */
+  SLAMHIP_EUNSUPPORTED = -2,/* size outside what the kernels are built for      */
+  SLAMHIP_EWORKSPACE = -3,  /* workspace missing or too small                   */
+  SLAMHIP_ELAUNCH = -4      /* HIP runtime reported an error at launch          */
+};
+
+/* Limits the kernels are built for. */
+#define SLAMHIP_MAX_DESC_BYTES 128      /* descriptor row length in bytes        */
+#define SLAMHIP_MAX_TRAIN_ROWS (1 << 21)/* train rows per pair (packed-key width)*/
+
+int slamhip_version(void);
+const char *slamhip_strerror(int code);
+
+/* Diagnostics only (kernel-variant benchmarks): knob 0 = matcher kernel variant
+ * (-1 auto), knob 1 = forced number of train splits (0 auto).  Process-global;
+ * not for use while other threads are inside the library. */
+int slamhip_tune(int knob, int value);
+
+/* ------------------------------------------------------------------------- */
+/* Hamming brute-force k=2 nearest neighbours.                               */
+/* Replaces cv2.BFMatcher(NORM_HAMMING).match / knnMatch(k=2) as called from */
+/* frontend/vision/descriptor_matcher.py:23-34 (match, k=1 = column 0 of the */
+/* result) and the commented knn_match/ratio_test call site at               */
+/* backend/optimizers/loop_closure.py:193-194.                               */
+/*                                                                           */
+/* For every query row i: the two train rows with the smallest Hamming       */
+/* distance, ties resolved towards the LOWEST train index (the order a       */
+/* sequential scan with a strict `<` insertion produces).                    */
+/*   d_idx2 [nq*2] int32 : train index of best, second best (-1 if absent)   */
+/*   d_dist2[nq*2] int32 : their distances in bits          (-1 if absent)   */
+/* Rows are `desc_bytes` long (1..128) and `row_stride` bytes apart.         */
+/* ------------------------------------------------------------------------- */
+/* Workspace size for a call with these totals; max_nq / max_nt are the largest
+ * single-pair row counts (= nq / nt for the unbatched call).  0 = bad input. */
+size_t slamhip_hamming_knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs,
+                                            int max_nq, int max_nt, int desc_bytes);
+
+int slamhip_hamming_knn2(const uint8_t *d_query, int nq, const uint8_t *d_train, int nt,
+                         int desc_bytes, int row_stride, int32_t *d_idx2, int32_t *d_dist2,
+                         void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Batched form: n_pairs independent (query set, train set) problems in one
+ * launch.  Pair p owns query rows [q_off[p], q_off[p+1]) and train rows
+ * [t_off[p], t_off[p+1]) of the concatenated descriptor arrays; train indices
+ * in d_idx2 are LOCAL to the pair.  d_q_off / d_t_off are device arrays of
+ * n_pairs+1 int32; max_nq / max_nt are host-side upper bounds on any single
+ * pair's row counts (they size the grid; a bound that is too small is an
+ * error the caller must avoid, it is not detectable on the host). */
+int slamhip_hamming_knn2_batched(const uint8_t *d_query, int nq_total, const uint8_t *d_train,
+                                 int nt_total, int desc_bytes, int row_stride,
+                                 const int32_t *d_q_off, const int32_t *d_t_off, int n_pairs,
+                                 int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
+                                 void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* Lowe ratio test on the k=2 result (loop_closure.py:194, `ratio_test(raw, ratio)`):
+ * keep[i] = 1 iff a second neighbour exists and
+ *           (double)dist2[2i] < ratio * (double)dist2[2i+1]. */
+int slamhip_ratio_test(const int32_t *d_dist2, int nq, double ratio, uint8_t *d_keep,
+                       void *stream);
+
+/* cv2.BFMatcher(crossCheck=True) semantics (descriptor_matcher.py:26 with
+ * cross_check=True).  Input: for every TRAIN row its best QUERY row and distance
+ * (the k=1 column of a train->query knn2 call, element stride 2).  Output per
+ * query row: among the train rows that chose it, the one with the smallest
+ * distance (lowest train index on ties), or -1.  */
+int slamhip_cross_check(const int32_t *d_t2q_idx2, const int32_t *d_t2q_dist2, int nt, int nq,
+                        int32_t *d_match_idx, int32_t *d_match_dist, void *stream);
+
+/* Stable ordering of matches by (distance, query index): the order of
+ * `sorted(matches, key=lambda x: x.distance)` at descriptor_matcher.py:34.
+ * d_dist has element stride `dist_stride` (2 to read column 0 of d_dist2).
+ * Entries with dist < 0 (no match) sort last.  d_order[r] = query index of the
+ * r-th match.  Segmented like the batched matcher when d_off != NULL
+ * (d_order values are local to the segment, written at segment offset). */
+int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total,
+                             const int32_t *d_off, int n_segments, int max_n,
+                             int32_t *d_order, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* Rectified-stereo filter + DLT triangulation, one match per lane.          */
+/* Replaces Triangulation.create_inlier_outlier_matches                      */
+/* (frontend/geometry/triangulation.py:96-109) and                           */
+/* Triangulation.triangulate_opencv -> cv2.triangulatePoints                 */
+/* (triangulation.py:76-87; loop_closure.py:237-249 for the fp64 form).      */
+/*                                                                           */
+/* Match k pairs left keypoint d_qidx[k] with right keypoint d_tidx[k]       */
+/* (NULL index arrays mean the identity: k-th left with k-th right).         */
+/*   keep[k] = |vR - vL| <= pix_thresh  &&  (uL - uR) >= disp_min  (fp64)    */
+/*   xyz[k]  = dehomogenised null vector of the 4x4 DLT system built from    */
+/*             P_left/P_right (host, 12 doubles each, row major), solved by  */
+/*             one-sided Jacobi in fp64.  out_fp64=0: the unit 4-vector is   */
+/*             rounded to fp32 and divided in fp32 (what float32 input gives */
+/*             in OpenCV); out_fp64=1: divided in fp64.                      */
+/* keypoints are (n,2) float32 (fp64 if kp_fp64=1).  d_keep may be NULL      */
+/* (no filtering: every match is triangulated).  If d_keep is given, xyz of  */
+/* rejected matches is written as 0.                                         */
+/* ------------------------------------------------------------------------- */
+int slamhip_stereo_filter_triangulate(const void *d_kp_left, const void *d_kp_right,
+                                      int kp_fp64, const int32_t *d_qidx,
+                                      const int32_t *d_tidx, int m, const double *P_left,
+                                      const double *P_right, double pix_thresh,
+                                      double disp_min, uint8_t *d_keep, void *d_xyz,
+                                      int out_fp64, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* PnP-RANSAC consensus scoring.                                             */
+/* Replaces the body of the loop in PnP.ransac_pnp_pair1                     */
+/* (frontend/geometry/pnp.py:132-143): PnP.project (pnp.py:94-99) for the    */
+/* left and right camera, compute_err (utils/graph_utils.py:7-11) and        */
+/* PnP.supporters_pair (pnp.py:86-91), for H hypotheses at once.             */
+/*                                                                           */
+/*   d_points  (n,3) float32 (fp64 if points_fp64=1) landmark coordinates    */
+/*   d_meas_l / d_meas_r (n,2) float32 measured pixels                       */
+/*   d_Rt      (h,3,4) fp64 hypotheses [R|t] (left camera extrinsics)        */
+/*   d_valid   (h) uint8 or NULL; 0 marks a failed minimal solve (count=-1)  */
+/*   K (9 doubles) and M_right (12 doubles) are HOST pointers.               */
+/*   d_counts  (h) int32 : number of points with                             */
+/*             err_L <= thresh && err_R <= thresh (no cheirality test).      */
+/* ------------------------------------------------------------------------- */
+int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_meas_l,
+                         const float *d_meas_r, int n, const double *d_Rt,
+                         const uint8_t *d_valid, int h, const double *K,
+                         const double *M_right, double thresh, int32_t *d_counts,
+                         void *stream);
+
+/* Inlier mask of ONE hypothesis (the `mask` of pnp.py:141-142). */
+int slamhip_ransac_mask(const void *d_points, int points_fp64, const float *d_meas_l,
+                        const float *d_meas_r, int n, const double *d_Rt_one,
+                        const double *K, const double *M_right, double thresh,
+                        uint8_t *d_mask, void *stream);
+
+/* The two small helpers the reference exposes on its own:
+ * PnP.project (pnp.py:94-99): pixels (n,2) fp64 = dehomogenised P @ [X,1];
+ * P is a HOST pointer to 12 doubles.  PnP.supporters_pair (pnp.py:86-91) with
+ * compute_err (utils/graph_utils.py:7-11): all inputs (n,2) fp64 on the device. */
+int slamhip_project(const void *d_points, int points_fp64, int n, const double *P,
+                    double *d_pixels, void *stream);
+int slamhip_supporters_pair(const double *d_meas_l, const double *d_proj_l,
+                            const double *d_meas_r, const double *d_proj_r, int n,
+                            double thresh, uint8_t *d_mask, void *stream);
+
+/* Sequential replay of the adaptive stopping rule of pnp.py:123-158 over the
+ * ordered hypothesis counts (count < 0 = failed solve, iteration still
+ * counted).  Writes 8 int32: d_result[0] = index of the winning hypothesis (-1
+ * if none had count > 0), [1] = its count, [2] = iterations executed, [3] =
+ * final n_iter_required, [4] = 1 if the reference would have raised
+ * `ValueError: math domain error` (every point an inlier -> log(0)); the
+ * replay then stops as if zero further iterations were required.  early_inliers < 0 disables the early exit.  Runs on the
+ * device so that no host round trip sits between scoring and the mask.  */
+int slamhip_ransac_replay(const int32_t *d_counts, int h, int n_points, double p_success,
+                          int n_iter_max, int early_inliers, int32_t *d_result,
+                          void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SLAMHIP_H */

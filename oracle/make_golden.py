@@ -1,0 +1,233 @@
+"""
+Generates tests/golden/*.npz.  Run in the build container only:
+
+    python oracle/make_golden.py
+
+Two kinds of vectors are written:
+
+ (A) REFERENCE-PINNED: outputs of the reference's own Python functions, imported
+     from /root/reference.  The reference modules `import cv2` / `import gtsam`
+     at module level; neither is installed, so empty placeholder modules are put
+     in sys.modules for the import only.  Only functions whose bodies are pure
+     NumPy are called (PnP.project, PnP.supporters_pair, compute_err,
+     homogenous, non_homogenous, Triangulation._build_single_camera_A_matrix,
+     Triangulation._build_A_matrix, Triangulation.create_inlier_outlier_matches,
+     CameraModel).  No cv2 behaviour is emulated.
+
+ (B) ORACLE-GENERATED (parity unpinned): outputs of oracle/slam_oracle.py for
+     the OpenCV-backed steps (Hamming kNN, DLT triangulation), kept so that a
+     later change of the oracle or of NumPy/LAPACK is detected.
+
+The reference itself never travels; only these small arrays do.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+from oracle import slam_oracle as so  # noqa: E402
+
+KITTI_P0 = [7.070912e02, 0, 6.018873e02, 0, 0, 7.070912e02, 1.831104e02, 0, 0, 0, 1, 0]
+KITTI_P1 = [7.070912e02, 0, 6.018873e02, -3.798145e02, 0, 7.070912e02, 1.831104e02, 0, 0, 0, 1, 0]
+
+
+def import_reference():
+    """Import the reference package as `slam` from /root/reference."""
+    ref = "/root/reference"
+    if not os.path.isdir(ref):
+        raise SystemExit("reference not mounted; golden vectors can only be made in the build container")
+    class _Absent(types.ModuleType):
+        # Attribute access only has to succeed so that `def f(x: gtsam.Pose3)`
+        # annotations evaluate at import; nothing returned here is ever called.
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return type(item, (), {})
+
+    for name in ("cv2", "gtsam"):
+        if name not in sys.modules:
+            sys.modules[name] = _Absent(name)
+    tmp = tempfile.mkdtemp(prefix="slamref_")
+    os.symlink(ref, os.path.join(tmp, "slam"))
+    sys.path.insert(0, tmp)
+    from slam.frontend.geometry.pnp import PnP  # type: ignore
+    from slam.frontend.geometry.triangulation import Triangulation  # type: ignore
+    from slam.frontend.io.camera_model import CameraModel  # type: ignore
+    from slam.utils import graph_utils  # type: ignore
+    return PnP, Triangulation, CameraModel, graph_utils
+
+
+class _KP:
+    def __init__(self, x, y):
+        self.pt = (float(np.float32(x)), float(np.float32(y)))
+
+
+class _M:
+    def __init__(self, q, t):
+        self.queryIdx, self.trainIdx = int(q), int(t)
+
+
+def scene(rng, cam, n, sigma=0.5, outliers=0.3):
+    X = np.column_stack([rng.uniform(-25, 25, n), rng.uniform(-3, 2, n), rng.uniform(4, 120, n)])
+    Xh = np.column_stack([X, np.ones(n)])
+    pl = Xh @ cam.P_left.T
+    pr = Xh @ cam.P_right.T
+    uvl = pl[:, :2] / pl[:, 2:3] + rng.normal(0, sigma, (n, 2))
+    uvr = pr[:, :2] / pr[:, 2:3] + rng.normal(0, sigma, (n, 2))
+    bad = rng.random(n) < outliers
+    uvr[bad] += rng.normal(0, 30, (int(bad.sum()), 2))
+    return X, uvl.astype(np.float32), uvr.astype(np.float32)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    PnP, Triangulation, CameraModel, gu = import_reference()
+
+    calib = os.path.join(tempfile.mkdtemp(), "calib.txt")
+    with open(calib, "w") as fh:
+        fh.write("P0: " + " ".join(repr(v) for v in KITTI_P0) + "\n")
+        fh.write("P1: " + " ".join(repr(v) for v in KITTI_P1) + "\n")
+    cam = CameraModel.from_kitti(calib)
+    rng = np.random.default_rng(20240511)
+
+    # ---- (A1) camera model
+    np.savez(os.path.join(OUT, "ref_camera.npz"), P0=np.array(KITTI_P0), P1=np.array(KITTI_P1),
+             K=cam.K, M_left=cam.M_left, M_right=cam.M_right, P_left=cam.P_left,
+             P_right=cam.P_right)
+
+    # ---- (A2) stereo filter decisions incl. exact boundary values
+    n = 400
+    _, kl, kr = scene(rng, cam, n, outliers=0.4)
+    # craft boundaries: |dv| == 4.0 exactly, just above; disparity == 1.2 (float32) and neighbours
+    kl[0] = (100.0, 50.0); kr[0] = (90.0, 54.0)                 # |dv| = 4.0 -> keep
+    kl[1] = (100.0, 50.0); kr[1] = (90.0, np.float32(54.000004))  # just above -> reject
+    kl[2] = (100.0, 50.0); kr[2] = (np.float32(100.0) - np.float32(1.2), 50.0)
+    kl[3] = (100.0, 50.0); kr[3] = (np.nextafter(np.float32(98.8), np.float32(200)), 50.0)
+    kl[4] = (100.0, 50.0); kr[4] = (np.nextafter(np.float32(98.8), np.float32(0)), 50.0)
+    kl[5] = (100.0, 46.0); kr[5] = (90.0, 50.0)                 # dv = -4.0 -> keep
+    kl[6] = (50.0, 10.0); kr[6] = (60.0, 10.0)                  # negative disparity
+    qidx = rng.permutation(n).astype(np.int32)
+    tidx = qidx.copy()
+    swap = rng.random(n) < 0.2
+    tidx[swap] = rng.integers(0, n, int(swap.sum()))
+    qidx[:7] = np.arange(7); tidx[:7] = np.arange(7)
+    tri = Triangulation(cam, disparity_min=1.2, pixel_thresh=4.0)
+    kpl = [_KP(*p) for p in kl]
+    kpr = [_KP(*p) for p in kr]
+    matches = [_M(q, t) for q, t in zip(qidx, tidx)]
+    inl, outl = tri.create_inlier_outlier_matches(matches, kpl, kpr)
+    keep = np.zeros(n, dtype=np.uint8)
+    inl_ids = {id(m) for m in inl}
+    for k, m in enumerate(matches):
+        keep[k] = 1 if id(m) in inl_ids else 0
+    np.savez(os.path.join(OUT, "ref_stereo_filter.npz"), kp_left=kl, kp_right=kr, qidx=qidx,
+             tidx=tidx, pixel_thresh=4.0, disparity_min=1.2, keep=keep)
+
+    # ---- (A3) own DLT builder rows (reference functions) + NumPy SVD solution
+    m = 300
+    X, uvl, uvr = scene(rng, cam, m, outliers=0.0)
+    A = np.empty((m, 4, 4))
+    for k in range(m):
+        a1 = tri._build_single_camera_A_matrix(float(uvl[k, 0]), float(uvl[k, 1]), cam.P_left)
+        a2 = tri._build_single_camera_A_matrix(float(uvr[k, 0]), float(uvr[k, 1]), cam.P_right)
+        A[k] = tri._build_A_matrix(a1, a2)
+    _, _, Vt = np.linalg.svd(A)
+    Xh = Vt[:, -1, :]
+    X_own = Xh[:, :3] / Xh[:, 3:4]
+    np.savez(os.path.join(OUT, "ref_dlt_own.npz"), kp_left=uvl, kp_right=uvr, A=A, X=X_own,
+             X_true=X)
+
+    # ---- (A4) project / compute_err / supporters_pair / homogenous on a scene with edge cases
+    npts = 320
+    X, uvl, uvr = scene(rng, cam, npts, outliers=0.3)
+    X32 = X.astype(np.float32)
+    X32[0] = (1.0, 0.5, -5.0)     # behind the camera: still projects (no cheirality test)
+    X32[1] = (0.3, 0.2, 1e-7)     # z ~ 0
+    pnp = PnP(cam, pixel_thresh=4.0)
+    ang = 0.01
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    Rt = np.hstack([R, np.array([[0.02], [-0.01], [-0.8]])])
+    H = 12
+    Rts = np.empty((H, 3, 4))
+    for h in range(H):
+        d = rng.normal(0, 1e-3 if h % 3 else 5e-2, 3)
+        Rts[h] = np.hstack([R, (Rt[:, 3] + d)[:, None]])
+    # measurements consistent with Rt (points are in the previous frame)
+    P_L = cam.K @ Rt
+    Rt_R = gu.non_homogenous(gu.homogenous(cam.M_right) @ gu.homogenous(Rt))
+    P_R = cam.K @ Rt_R
+    with np.errstate(all="ignore"):
+        mL = (PnP.project(X32, P_L) + rng.normal(0, 0.7, (npts, 2))).astype(np.float32)
+        mR = (PnP.project(X32, P_R) + rng.normal(0, 0.7, (npts, 2))).astype(np.float32)
+        bad = rng.random(npts) < 0.3
+        mL[bad] += rng.normal(0, 25, (int(bad.sum()), 2)).astype(np.float32)
+        mL = np.nan_to_num(mL, nan=0.0, posinf=1e6, neginf=-1e6)
+        mR = np.nan_to_num(mR, nan=0.0, posinf=1e6, neginf=-1e6)
+        projL = np.empty((H, npts, 2)); projR = np.empty((H, npts, 2))
+        errL = np.empty((H, npts)); errR = np.empty((H, npts))
+        masks = np.empty((H, npts), dtype=np.uint8)
+        M_right_h = gu.homogenous(cam.M_right)
+        for h in range(H):
+            PL_h = cam.K @ Rts[h]
+            projL[h] = PnP.project(X32, PL_h)
+            RtR_h = gu.non_homogenous(M_right_h @ gu.homogenous(Rts[h]))
+            PR_h = cam.K @ RtR_h
+            projR[h] = PnP.project(X32, PR_h)
+            errL[h] = gu.compute_err(mL, projL[h])
+            errR[h] = gu.compute_err(mR, projR[h])
+            masks[h] = pnp.supporters_pair(mL, projL[h], mR, projR[h]).astype(np.uint8)
+    np.savez(os.path.join(OUT, "ref_ransac_score.npz"), K=cam.K, M_right=cam.M_right, X=X32,
+             meas_L=mL, meas_R=mR, Rts=Rts, pixel_thresh=4.0, proj_L=projL, proj_R=projR,
+             err_L=errL, err_R=errR, masks=masks, counts=masks.sum(axis=1).astype(np.int32))
+
+    # ---- (B1) Hamming top-2, crafted ties / duplicates / tiny train sets (oracle-generated)
+    cases = {}
+    for name, (nq, nt, D) in {"akaze": (300, 257, 61), "orb": (200, 130, 32),
+                              "nt1": (17, 1, 61), "nt2": (17, 2, 61)}.items():
+        t = rng.integers(0, 256, (nt, D), dtype=np.uint8)
+        q = rng.integers(0, 256, (nq, D), dtype=np.uint8)
+        if nt > 4:
+            t[5] = t[3]; t[nt - 1] = t[3]            # exact duplicates -> ties
+            q[0] = t[3]                              # distance 0 to three rows
+            q[1] = t[3]; q[1, 0] ^= 1                # distance 1 to three rows
+            q[2:40] = t[rng.integers(0, nt, 38)] ^ (rng.random((38, D)) < 0.02).astype(np.uint8)
+        idx2, dist2 = so.hamming_knn2(q, t)
+        idx2s, dist2s = so.hamming_knn2_sequential(q[:40], t)
+        assert (idx2[:40] == idx2s).all() and (dist2[:40] == dist2s).all()
+        cases[f"{name}_q"], cases[f"{name}_t"] = q, t
+        cases[f"{name}_idx2"], cases[f"{name}_dist2"] = idx2, dist2
+    np.savez_compressed(os.path.join(OUT, "oracle_hamming.npz"), **cases)
+
+    # ---- (B2) DLT in cv2 row order via NumPy SVD (oracle-generated)
+    X, uvl, uvr = scene(rng, cam, 256, outliers=0.1)
+    np.savez(os.path.join(OUT, "oracle_dlt_cv.npz"), kp_left=uvl, kp_right=uvr,
+             P_left=cam.P_left, P_right=cam.P_right,
+             X32=so.triangulate_cv(cam.P_left, cam.P_right, uvl, uvr, out_fp64=False),
+             X64=so.triangulate_cv(cam.P_left, cam.P_right, uvl.astype(np.float64),
+                                   uvr.astype(np.float64), out_fp64=True))
+
+    # ---- (B3) RANSAC replay traces (control flow of pnp.py:110-160, oracle-generated)
+    traces = {}
+    for i, (N, lo, hi) in enumerate([(550, 0.2, 0.7), (550, 0.0, 0.15), (120, 0.5, 0.95), (64, 0.9, 1.0)]):
+        counts = (rng.uniform(lo, hi, 2500) * N).astype(np.int32)
+        counts[rng.random(2500) < 0.03] = -1
+        if i == 3:
+            counts = np.minimum(counts, N - 1)
+        res = so.ransac_replay(counts, N, 0.99999, 2500, None)
+        traces[f"counts{i}"], traces[f"N{i}"], traces[f"res{i}"] = counts, N, np.array(res)
+    traces["idx4_seed12345_N550"] = so.sample_indices(550, 64)
+    np.savez_compressed(os.path.join(OUT, "oracle_ransac_replay.npz"), **traces)
+    print("golden vectors written to", OUT)
+
+
+if __name__ == "__main__":
+    main()

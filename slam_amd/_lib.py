@@ -1,0 +1,81 @@
+"""ctypes binding of libslamhip.so (the C ABI declared in include/slamhip.h).
+
+The library is the only compute path: if it is missing, import of this module
+raises.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+
+OK, EINVAL, EUNSUPPORTED, EWORKSPACE, ELAUNCH = 0, -1, -2, -3, -4
+
+
+class SlamHipError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        super().__init__(f"{where}: {strerror(code)} (code {code})")
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C slam_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "slam_amd has no CPU fallback."
+        )
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+_dp = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); kept in the order of include/slamhip.h
+SIGNATURES = {
+    "slamhip_version": (_i, []),
+    "slamhip_strerror": (C.c_char_p, [_i]),
+    "slamhip_tune": (_i, [_i, _i]),
+    "slamhip_hamming_knn2_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
+    "slamhip_hamming_knn2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "slamhip_hamming_knn2_batched": (
+        _i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "slamhip_ratio_test": (_i, [_vp, _i, _d, _vp, _vp]),
+    "slamhip_cross_check": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "slamhip_sort_by_distance": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
+    "slamhip_stereo_filter_triangulate": (
+        _i, [_vp, _vp, _i, _vp, _vp, _i, _dp, _dp, _d, _d, _vp, _vp, _i, _vp]),
+    "slamhip_ransac_score": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _dp, _dp, _d, _vp, _vp]),
+    "slamhip_ransac_mask": (_i, [_vp, _i, _vp, _vp, _i, _vp, _dp, _dp, _d, _vp, _vp]),
+    "slamhip_project": (_i, [_vp, _i, _i, _dp, _vp, _vp]),
+    "slamhip_supporters_pair": (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp]),
+    "slamhip_ransac_replay": (_i, [_vp, _i, _i, _d, _i, _i, _vp, _vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def strerror(code: int) -> str:
+    return lib.slamhip_strerror(int(code)).decode()
+
+
+def check(code: int, where: str) -> None:
+    if code != OK:
+        raise SlamHipError(code, where)
+
+
+def host_doubles(arr, n: int):
+    """Row-major float64 host block as a ctypes double* (keeps a reference)."""
+    import numpy as np
+
+    a = np.ascontiguousarray(np.asarray(arr, dtype=np.float64).reshape(-1))
+    if a.size != n:
+        raise ValueError(f"expected {n} values, got {a.size}")
+    return a.ctypes.data_as(_dp), a

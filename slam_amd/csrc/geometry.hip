@@ -1,0 +1,179 @@
+// Rectified-stereo row/disparity filter fused with DLT triangulation for
+// gfx950: one match per lane, everything in fp64 registers.
+//
+// Reference arithmetic being reproduced:
+//   filter : frontend/geometry/triangulation.py:96-109
+//            keep = abs(vR - vL) <= pixel_thresh and (uL - uR) >= disparity_min
+//            (float32 pixel coordinates widened to fp64 before the arithmetic)
+//   DLT    : frontend/geometry/triangulation.py:76-87 -> cv2.triangulatePoints:
+//            rows  x*P[2] - P[0],  y*P[2] - P[1]  for the left then the right
+//            camera, right singular vector of the smallest singular value,
+//            then X = Xh[:3] / Xh[3].
+// The 4x4 system is solved with one-sided (Hestenes) Jacobi rotations on the
+// columns of A, accumulating V; it never forms A^T A, so the small singular
+// value keeps full relative accuracy.
+#include "common.h"
+
+namespace {
+
+struct CamPair {
+  double PL[12];
+  double PR[12];
+};
+
+constexpr int kMaxSweeps = 12;
+
+// Rotate columns p and q of the 4x4 A (a[row][col]) and of V so that the two
+// columns of A become orthogonal.  Returns true when a rotation was applied.
+template <int P, int Qc>
+__device__ __forceinline__ bool jacobi_pair(double (&a)[4][4], double (&v)[4][4]) {
+  double alpha = 0.0, beta = 0.0, gamma = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    alpha = fma(a[i][P], a[i][P], alpha);
+    beta = fma(a[i][Qc], a[i][Qc], beta);
+    gamma = fma(a[i][P], a[i][Qc], gamma);
+  }
+  // Columns already orthogonal to working precision.
+  if (fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta) || gamma == 0.0) return false;
+  const double zeta = (beta - alpha) / (2.0 * gamma);
+  const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
+  const double c = 1.0 / sqrt(fma(t, t, 1.0));
+  const double s = c * t;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double ap = a[i][P], aq = a[i][Qc];
+    a[i][P] = c * ap - s * aq;
+    a[i][Qc] = s * ap + c * aq;
+    const double vp = v[i][P], vq = v[i][Qc];
+    v[i][P] = c * vp - s * vq;
+    v[i][Qc] = s * vp + c * vq;
+  }
+  return true;
+}
+
+// Unit right singular vector of the smallest singular value of A.
+__device__ __forceinline__ void smallest_right_singular_vector(double (&a)[4][4], double (&x)[4]) {
+  double v[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
+
+  for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
+    bool any = false;
+    any |= jacobi_pair<0, 1>(a, v);
+    any |= jacobi_pair<0, 2>(a, v);
+    any |= jacobi_pair<0, 3>(a, v);
+    any |= jacobi_pair<1, 2>(a, v);
+    any |= jacobi_pair<1, 3>(a, v);
+    any |= jacobi_pair<2, 3>(a, v);
+    if (!any) break;
+  }
+  double n[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    n[j] = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) n[j] = fma(a[i][j], a[i][j], n[j]);
+  }
+  // Column with the smallest norm (lowest index on exact ties).
+  int k = 0;
+  double best = n[0];
+#pragma unroll
+  for (int j = 1; j < 4; ++j)
+    if (n[j] < best) { best = n[j]; k = j; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    x[i] = k == 0 ? v[i][0] : (k == 1 ? v[i][1] : (k == 2 ? v[i][2] : v[i][3]));
+  // V is a product of rotations, so the column is unit length up to rounding;
+  // renormalise so the fp32 rounding below sees a unit vector like an SVD's.
+  const double inv = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) x[i] *= inv;
+}
+
+template <typename KP>
+__global__ __launch_bounds__(256) void filter_triangulate_kernel(
+    const KP *__restrict__ kp_left, const KP *__restrict__ kp_right,
+    const int32_t *__restrict__ qidx, const int32_t *__restrict__ tidx, int m, CamPair cam,
+    double pix_thresh, double disp_min, uint8_t *__restrict__ keep, void *__restrict__ xyz,
+    int out_fp64) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  const int li = qidx ? qidx[k] : k;
+  const int ri = tidx ? tidx[k] : k;
+  const double uL = (double)kp_left[2 * (size_t)li + 0];
+  const double vL = (double)kp_left[2 * (size_t)li + 1];
+  const double uR = (double)kp_right[2 * (size_t)ri + 0];
+  const double vR = (double)kp_right[2 * (size_t)ri + 1];
+
+  bool ok = true;
+  if (keep != nullptr) {
+    ok = (fabs(vR - vL) <= pix_thresh) && ((uL - uR) >= disp_min);
+    keep[k] = ok ? 1 : 0;
+  }
+
+  double X = 0.0, Y = 0.0, Z = 0.0;
+  float Xf = 0.f, Yf = 0.f, Zf = 0.f;
+  if (ok) {
+    double a[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      a[0][c] = uL * cam.PL[8 + c] - cam.PL[0 + c];
+      a[1][c] = vL * cam.PL[8 + c] - cam.PL[4 + c];
+      a[2][c] = uR * cam.PR[8 + c] - cam.PR[0 + c];
+      a[3][c] = vR * cam.PR[8 + c] - cam.PR[4 + c];
+    }
+    double x[4];
+    smallest_right_singular_vector(a, x);
+    if (out_fp64) {
+      X = x[0] / x[3];
+      Y = x[1] / x[3];
+      Z = x[2] / x[3];
+    } else {
+      const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
+      Xf = x0 / x3;
+      Yf = x1 / x3;
+      Zf = x2 / x3;
+    }
+  }
+  if (out_fp64) {
+    double *o = reinterpret_cast<double *>(xyz) + 3 * (size_t)k;
+    o[0] = X; o[1] = Y; o[2] = Z;
+  } else {
+    float *o = reinterpret_cast<float *>(xyz) + 3 * (size_t)k;
+    o[0] = Xf; o[1] = Yf; o[2] = Zf;
+  }
+}
+
+}  // namespace
+
+extern "C" int slamhip_stereo_filter_triangulate(const void *d_kp_left, const void *d_kp_right,
+                                                 int kp_fp64, const int32_t *d_qidx,
+                                                 const int32_t *d_tidx, int m,
+                                                 const double *P_left, const double *P_right,
+                                                 double pix_thresh, double disp_min,
+                                                 uint8_t *d_keep, void *d_xyz, int out_fp64,
+                                                 void *stream) {
+  if (m < 0) return SLAMHIP_EINVAL;
+  if (m == 0) return SLAMHIP_OK;
+  if (!d_kp_left || !d_kp_right || !P_left || !P_right || !d_xyz) return SLAMHIP_EINVAL;
+  CamPair cam;
+  for (int i = 0; i < 12; ++i) {
+    cam.PL[i] = P_left[i];
+    cam.PR[i] = P_right[i];
+  }
+  const dim3 grid(slamhip_ceil_div(m, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (kp_fp64)
+    hipLaunchKernelGGL(filter_triangulate_kernel<double>, grid, block, 0, st,
+                       (const double *)d_kp_left, (const double *)d_kp_right, d_qidx, d_tidx, m,
+                       cam, pix_thresh, disp_min, d_keep, d_xyz, out_fp64);
+  else
+    hipLaunchKernelGGL(filter_triangulate_kernel<float>, grid, block, 0, st,
+                       (const float *)d_kp_left, (const float *)d_kp_right, d_qidx, d_tidx, m,
+                       cam, pix_thresh, disp_min, d_keep, d_xyz, out_fp64);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}

@@ -1,0 +1,483 @@
+// Hamming brute-force top-2 matcher for gfx950 (MI355X).
+//
+// Work decomposition
+//   lane      = Q query descriptors held in registers (W dwords each)
+//   wave      = 64*Q queries; walks a slice of the train rows, one row at a
+//               time, the row being wave-uniform (scalar loads -> SGPR operands,
+//               or an LDS-staged tile read with a broadcast address)
+//   block     = 256 threads = 256*Q consecutive queries of one pair
+//   grid      = (query blocks, train splits, pairs)
+// Per (query, train row): W x (v_xor_b32 + v_bcnt_u32_b32 accumulate), then the
+// distance and the train index are packed into one 32-bit key
+//   key = dist << 21 | train_index
+// so that "smaller distance, then lower train index" is plain unsigned order and
+// the running top-2 update is v_med3_u32 + v_min_u32.  Every train split writes
+// its (best, second) key pair; a merge kernel folds the splits in index order.
+//
+// Tie rule = cv2.BFMatcher / batchDistance: scanning train rows in ascending
+// order with a strict `<` insertion keeps the lowest train index among equal
+// distances, for the best and for the second best
+// (call site: frontend/vision/descriptor_matcher.py:33 of the reference).
+#include "common.h"
+
+namespace {
+
+constexpr int kKeyShift = 21;
+constexpr uint32_t kIdxMask = (1u << kKeyShift) - 1u;
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr int kThreads = 256;
+constexpr int kTileRows = 128;  // LDS variant: train rows staged per tile
+constexpr int kMaxSplits = 64;
+
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t r;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// Running top-2 of unsigned keys; invariant b1 <= b2.
+__device__ __forceinline__ void top2_push(uint32_t &b1, uint32_t &b2, uint32_t key) {
+  b2 = umed3(b1, b2, key);
+  b1 = min(b1, key);
+}
+
+// ---------------------------------------------------------------------------
+// Row packing: (n, desc_bytes) rows `stride` bytes apart -> (n, W) dwords,
+// zero padded.  Handles both descriptor sets of a call in one launch.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_rows_kernel(
+    const uint8_t *__restrict__ src_a, int n_a, uint32_t *__restrict__ dst_a,
+    const uint8_t *__restrict__ src_b, int n_b, uint32_t *__restrict__ dst_b, int desc_bytes,
+    int stride, int W) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total_a = (long long)n_a * W;
+  const long long total = total_a + (long long)n_b * W;
+  if (gid >= total) return;
+  const uint8_t *src;
+  uint32_t *dst;
+  long long g;
+  if (gid < total_a) { src = src_a; dst = dst_a; g = gid; }
+  else { src = src_b; dst = dst_b; g = gid - total_a; }
+  const long long r = g / W;
+  const int w = (int)(g - r * W);
+  const uint8_t *p = src + r * (long long)stride + 4 * w;
+  uint32_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; ++b)
+    if (4 * w + b < desc_bytes) v |= (uint32_t)p[b] << (8 * b);
+  dst[g] = v;
+}
+
+// ---------------------------------------------------------------------------
+// Main kernel.
+// ---------------------------------------------------------------------------
+template <int W, int Q, bool USE_LDS>
+__global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
+    const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
+    const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off, int nq_single,
+    int nt_single, int nq_total, uint2 *__restrict__ partial, int32_t *__restrict__ idx2,
+    int32_t *__restrict__ dist2) {
+  const int pair = blockIdx.z;
+  int q0 = 0, nq = nq_single, t0 = 0, nt = nt_single;
+  if (q_off != nullptr) {
+    q0 = q_off[pair];
+    nq = q_off[pair + 1] - q0;
+    t0 = t_off[pair];
+    nt = t_off[pair + 1] - t0;
+  }
+  const int qblk = blockIdx.x * (kThreads * Q);
+  if (qblk >= nq) return;  // block-uniform
+
+  const int n_splits = gridDim.y;
+  const int split = blockIdx.y;
+  const int rps = (nt + n_splits - 1) / n_splits;
+  const int r_begin = min(nt, split * rps);
+  const int r_end = min(nt, r_begin + rps);
+
+  // Queries -> registers.  Lanes past the end re-read the last row (their
+  // results are never stored).
+  uint32_t qv[Q][W];
+  int qrow[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    qrow[q] = qblk + q * kThreads + (int)threadIdx.x;
+    const int r = min(qrow[q], nq - 1);
+    const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + r) * W);
+#pragma unroll
+    for (int w4 = 0; w4 < W / 4; ++w4) {
+      const uint4 v = src[w4];
+      qv[q][4 * w4 + 0] = v.x;
+      qv[q][4 * w4 + 1] = v.y;
+      qv[q][4 * w4 + 2] = v.z;
+      qv[q][4 * w4 + 3] = v.w;
+    }
+  }
+
+  uint32_t b1[Q], b2[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) b1[q] = b2[q] = kNoKey;
+
+  if constexpr (USE_LDS) {
+    __shared__ uint4 tile[kTileRows * W / 4];
+    for (int tile_begin = r_begin; tile_begin < r_end; tile_begin += kTileRows) {
+      const int rows = min(kTileRows, r_end - tile_begin);
+      __syncthreads();
+      const uint4 *src = reinterpret_cast<const uint4 *>(tp + (size_t)(t0 + tile_begin) * W);
+      for (int i = threadIdx.x; i < rows * (W / 4); i += kThreads) tile[i] = src[i];
+      __syncthreads();
+      for (int jj = 0; jj < rows; ++jj) {
+        uint32_t tw[W];
+#pragma unroll
+        for (int w4 = 0; w4 < W / 4; ++w4) {
+          const uint4 v = tile[jj * (W / 4) + w4];
+          tw[4 * w4 + 0] = v.x;
+          tw[4 * w4 + 1] = v.y;
+          tw[4 * w4 + 2] = v.z;
+          tw[4 * w4 + 3] = v.w;
+        }
+        const uint32_t jidx = (uint32_t)(tile_begin + jj);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          uint32_t acc = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) acc += __builtin_popcount(tw[w] ^ qv[q][w]);
+          top2_push(b1[q], b2[q], (acc << kKeyShift) | jidx);
+        }
+      }
+    }
+  } else {
+    // Wave-uniform train row: the compiler turns these loads into s_load_dwordx*
+    // and feeds the SGPRs straight into v_xor_b32.
+    // The next row is fetched into a second SGPR set before the current one is
+    // consumed, so the scalar-load latency overlaps the 2*W*Q VALU ops of a row.
+    if (r_begin < r_end) {
+      const uint32_t *trow = tp + (size_t)(t0 + r_begin) * W;
+      const uint32_t *tlast = tp + (size_t)(t0 + r_end - 1) * W;
+      uint32_t cur[W];
+#pragma unroll
+      for (int w = 0; w < W; ++w) cur[w] = trow[w];
+      for (int j = r_begin; j < r_end; ++j) {
+        trow = (trow == tlast) ? trow : trow + W;
+        uint32_t nxt[W];
+#pragma unroll
+        for (int w = 0; w < W; ++w) nxt[w] = trow[w];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          uint32_t acc = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) acc += __builtin_popcount(cur[w] ^ qv[q][w]);
+          top2_push(b1[q], b2[q], (acc << kKeyShift) | (uint32_t)j);
+        }
+#pragma unroll
+        for (int w = 0; w < W; ++w) cur[w] = nxt[w];
+      }
+    }
+  }
+
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    if (qrow[q] >= nq) continue;
+    const size_t row = (size_t)(q0 + qrow[q]);
+    if (n_splits == 1) {
+      idx2[2 * row + 0] = b1[q] == kNoKey ? -1 : (int32_t)(b1[q] & kIdxMask);
+      idx2[2 * row + 1] = b2[q] == kNoKey ? -1 : (int32_t)(b2[q] & kIdxMask);
+      dist2[2 * row + 0] = b1[q] == kNoKey ? -1 : (int32_t)(b1[q] >> kKeyShift);
+      dist2[2 * row + 1] = b2[q] == kNoKey ? -1 : (int32_t)(b2[q] >> kKeyShift);
+    } else {
+      partial[(size_t)split * nq_total + row] = make_uint2(b1[q], b2[q]);
+    }
+  }
+}
+
+// Folds the per-split key pairs.  One thread per query row; reads are
+// coalesced across rows for every split.
+__global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restrict__ partial,
+                                                            int nq_total, int n_splits,
+                                                            int32_t *__restrict__ idx2,
+                                                            int32_t *__restrict__ dist2) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nq_total) return;
+  uint32_t b1 = kNoKey, b2 = kNoKey;
+  for (int s = 0; s < n_splits; ++s) {
+    const uint2 p = partial[(size_t)s * nq_total + row];
+    top2_push(b1, b2, p.x);
+    top2_push(b1, b2, p.y);
+  }
+  int2 oi, od;
+  oi.x = b1 == kNoKey ? -1 : (int32_t)(b1 & kIdxMask);
+  oi.y = b2 == kNoKey ? -1 : (int32_t)(b2 & kIdxMask);
+  od.x = b1 == kNoKey ? -1 : (int32_t)(b1 >> kKeyShift);
+  od.y = b2 == kNoKey ? -1 : (int32_t)(b2 >> kKeyShift);
+  reinterpret_cast<int2 *>(idx2)[row] = oi;
+  reinterpret_cast<int2 *>(dist2)[row] = od;
+}
+
+__global__ __launch_bounds__(256) void ratio_test_kernel(const int32_t *__restrict__ dist2, int nq,
+                                                         double ratio,
+                                                         uint8_t *__restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const int2 d = reinterpret_cast<const int2 *>(dist2)[i];
+  keep[i] = (d.x >= 0 && d.y >= 0 && (double)d.x < ratio * (double)d.y) ? 1 : 0;
+}
+
+// crossCheck=True fold.  One thread per query row scans the train->query
+// result; nt is a few thousand, so the O(nq*nt) scan of 8-byte entries is a
+// small fraction of the distance work that produced it, and the ascending scan
+// gives the lowest-train-index tie rule for free.
+__global__ __launch_bounds__(256) void cross_check_kernel(const int32_t *__restrict__ t2q_idx2,
+                                                          const int32_t *__restrict__ t2q_dist2,
+                                                          int nt, int nq,
+                                                          int32_t *__restrict__ match_idx,
+                                                          int32_t *__restrict__ match_dist) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= nq) return;
+  int best_t = -1, best_d = 0x7FFFFFFF;
+  for (int t = 0; t < nt; ++t) {
+    const int who = t2q_idx2[2 * t];  // wave-uniform address -> scalar load
+    const int d = t2q_dist2[2 * t];
+    if (who == qi && d < best_d) {
+      best_d = d;
+      best_t = t;
+    }
+  }
+  match_idx[qi] = best_t;
+  match_dist[qi] = best_t < 0 ? -1 : best_d;
+}
+
+// ---------------------------------------------------------------------------
+// Stable order by (distance, query index) through rank counting: the keys
+// (dist << 21 | index) are unique, so rank(i) = #{j : key_j < key_i} and the
+// sorted sequence is order[rank(i)] = i.  2 VALU ops per (i, j) pair, all j
+// wave-uniform.  One block covers 256 i's of one segment and all j of that
+// segment.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t *__restrict__ dist,
+                                                        int dist_stride, int n_single,
+                                                        const int32_t *__restrict__ off,
+                                                        int32_t *__restrict__ order) {
+  __shared__ __align__(16) uint32_t keys[1024];
+  const int seg = blockIdx.y;
+  int s0 = 0, n = n_single;
+  if (off != nullptr) {
+    s0 = off[seg];
+    n = off[seg + 1] - s0;
+  }
+  const int i0 = blockIdx.x * 256;
+  if (i0 >= n) return;
+  const int i = i0 + (int)threadIdx.x;
+  uint32_t my = kNoKey;
+  if (i < n) {
+    const int d = dist[(size_t)(s0 + i) * dist_stride];
+    my = ((d < 0 ? 2047u : (uint32_t)d) << kKeyShift) | (uint32_t)i;
+  }
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 1024) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += 256) {
+      const int j = j0 + k;
+      uint32_t key = kNoKey;
+      if (j < n) {
+        const int d = dist[(size_t)(s0 + j) * dist_stride];
+        key = ((d < 0 ? 2047u : (uint32_t)d) << kKeyShift) | (uint32_t)j;
+      }
+      keys[k] = key;
+    }
+    __syncthreads();
+    const int lim = min(1024, n - j0);
+    const int lim4 = lim & ~3;
+    int k = 0;
+    for (; k < lim4; k += 4) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(&keys[k]);
+      rank += (v.x < my) + (v.y < my) + (v.z < my) + (v.w < my);
+    }
+    for (; k < lim; ++k) rank += keys[k] < my;
+  }
+  if (i < n) order[s0 + rank] = i;
+}
+
+struct MatchPlan {
+  int W, Q, qblocks, splits;
+  bool use_lds;
+  size_t off_qp, off_tp, off_part, total;
+};
+
+int g_force_variant = -1;  // diagnostics: -1 auto, bit0 = LDS, bits 1.. = Q
+int g_force_splits = 0;
+
+MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
+                    int desc_bytes) {
+  MatchPlan p;
+  p.W = slamhip_packed_words(desc_bytes);
+  p.use_lds = false;
+  p.Q = (p.W <= 16 && (long long)max_nq * n_pairs >= 4096) ? 2 : 1;
+  if (g_force_variant >= 0) {
+    p.use_lds = (g_force_variant & 1) != 0;
+    p.Q = (g_force_variant >> 1) == 2 && p.W <= 16 ? 2 : 1;
+  }
+  p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, kThreads * p.Q);
+  const long long base_blocks = (long long)p.qblocks * (n_pairs > 0 ? n_pairs : 1);
+  const long long target = 2048;  // 8 blocks of 4 waves per CU
+  long long s = (target + base_blocks - 1) / base_blocks;
+  const int by_rows = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, 32);
+  if (s > by_rows) s = by_rows;
+  if (s > kMaxSplits) s = kMaxSplits;
+  if (s < 1) s = 1;
+  if (g_force_splits > 0) s = g_force_splits > kMaxSplits ? kMaxSplits : g_force_splits;
+  p.splits = (int)s;
+  size_t o = 0;
+  p.off_qp = o;
+  o = slamhip_align_up(o + (size_t)nq_total * p.W * 4, 256);
+  p.off_tp = o;
+  o = slamhip_align_up(o + (size_t)nt_total * p.W * 4, 256);
+  p.off_part = o;
+  o = slamhip_align_up(o + (size_t)kMaxSplits * nq_total * sizeof(uint2), 256);
+  p.total = o + 256;
+  return p;
+}
+
+template <int W, int Q, bool L>
+void launch_top2(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp,
+                 const int32_t *q_off, const int32_t *t_off, int nq, int nt, int nq_total,
+                 uint2 *part, int32_t *idx2, int32_t *dist2) {
+  hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L>), grid, dim3(kThreads), 0, st, qp, tp, q_off,
+                     t_off, nq, nt, nq_total, part, idx2, dist2);
+}
+
+int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total,
+             int desc_bytes, int row_stride, const int32_t *d_q_off, const int32_t *d_t_off,
+             int n_pairs, int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
+             void *d_workspace, size_t workspace_bytes, void *stream) {
+  if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
+    return SLAMHIP_EINVAL;
+  if (desc_bytes < 1 || row_stride < desc_bytes) return SLAMHIP_EINVAL;
+  if (desc_bytes > SLAMHIP_MAX_DESC_BYTES || max_nt > SLAMHIP_MAX_TRAIN_ROWS ||
+      max_nq > SLAMHIP_MAX_TRAIN_ROWS)
+    return SLAMHIP_EUNSUPPORTED;
+  if (n_pairs > 65535) return SLAMHIP_EUNSUPPORTED;
+  if (nq_total == 0) return SLAMHIP_OK;
+  if (!d_query || !d_idx2 || !d_dist2 || (nt_total > 0 && !d_train)) return SLAMHIP_EINVAL;
+  if (n_pairs > 1 && (!d_q_off || !d_t_off)) return SLAMHIP_EINVAL;
+  if (max_nq == 0) return SLAMHIP_OK;
+  const MatchPlan p = make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes);
+  if (!d_workspace || workspace_bytes < p.total) return SLAMHIP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+
+  // 256-byte align the workspace base ourselves.
+  uintptr_t base = ((uintptr_t)d_workspace + 255) & ~(uintptr_t)255;
+  uint32_t *qp = (uint32_t *)(base + p.off_qp);
+  uint32_t *tp = (uint32_t *)(base + p.off_tp);
+  uint2 *part = (uint2 *)(base + p.off_part);
+
+  {
+    const long long total = ((long long)nq_total + nt_total) * p.W;
+    const int blocks = (int)((total + 255) / 256);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, d_query, nq_total, qp,
+                       d_train, nt_total, tp, desc_bytes, row_stride, p.W);
+    SLAMHIP_CHECK_LAUNCH();
+  }
+
+  const dim3 grid(p.qblocks, p.splits, n_pairs);
+  const int nqs = d_q_off ? 0 : nq_total, nts = d_q_off ? 0 : nt_total;
+#define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
+  launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_t_off, nqs, nts, nq_total, part, d_idx2, \
+                          d_dist2)
+  if (p.W == 8) {
+    if (p.Q == 2) { if (p.use_lds) SLAMHIP_DISPATCH(8, 2, true); else SLAMHIP_DISPATCH(8, 2, false); }
+    else          { if (p.use_lds) SLAMHIP_DISPATCH(8, 1, true); else SLAMHIP_DISPATCH(8, 1, false); }
+  } else if (p.W == 16) {
+    if (p.Q == 2) { if (p.use_lds) SLAMHIP_DISPATCH(16, 2, true); else SLAMHIP_DISPATCH(16, 2, false); }
+    else          { if (p.use_lds) SLAMHIP_DISPATCH(16, 1, true); else SLAMHIP_DISPATCH(16, 1, false); }
+  } else {
+    if (p.use_lds) SLAMHIP_DISPATCH(32, 1, true); else SLAMHIP_DISPATCH(32, 1, false);
+  }
+#undef SLAMHIP_DISPATCH
+  SLAMHIP_CHECK_LAUNCH();
+
+  if (p.splits > 1) {
+    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(nq_total, 256)), dim3(256), 0,
+                       st, part, nq_total, p.splits, d_idx2, d_dist2);
+    SLAMHIP_CHECK_LAUNCH();
+  }
+  return SLAMHIP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Diagnostics knob used by the kernel-variant benchmark: knob 0 = kernel
+// variant (-1 auto; bit0 LDS-staged train tile, value>>1 = queries per lane),
+// knob 1 = forced number of train splits (0 auto).
+int slamhip_tune(int knob, int value) {
+  if (knob == 0) g_force_variant = value;
+  else if (knob == 1) g_force_splits = value;
+  else return SLAMHIP_EINVAL;
+  return SLAMHIP_OK;
+}
+
+size_t slamhip_hamming_knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq,
+                                            int max_nt, int desc_bytes) {
+  if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || desc_bytes < 1 ||
+      desc_bytes > SLAMHIP_MAX_DESC_BYTES)
+    return 0;
+  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes).total;
+}
+
+int slamhip_hamming_knn2(const uint8_t *d_query, int nq, const uint8_t *d_train, int nt,
+                         int desc_bytes, int row_stride, int32_t *d_idx2, int32_t *d_dist2,
+                         void *d_workspace, size_t workspace_bytes, void *stream) {
+  return run_knn2(d_query, nq, d_train, nt, desc_bytes, row_stride, nullptr, nullptr, 1, nq, nt,
+                  d_idx2, d_dist2, d_workspace, workspace_bytes, stream);
+}
+
+int slamhip_hamming_knn2_batched(const uint8_t *d_query, int nq_total, const uint8_t *d_train,
+                                 int nt_total, int desc_bytes, int row_stride,
+                                 const int32_t *d_q_off, const int32_t *d_t_off, int n_pairs,
+                                 int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
+                                 void *d_workspace, size_t workspace_bytes, void *stream) {
+  if (!d_q_off || !d_t_off) return SLAMHIP_EINVAL;
+  return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
+                  n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, stream);
+}
+
+int slamhip_ratio_test(const int32_t *d_dist2, int nq, double ratio, uint8_t *d_keep,
+                       void *stream) {
+  if (nq < 0) return SLAMHIP_EINVAL;
+  if (nq == 0) return SLAMHIP_OK;
+  if (!d_dist2 || !d_keep) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(ratio_test_kernel, dim3(slamhip_ceil_div(nq, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_dist2, nq, ratio, d_keep);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_cross_check(const int32_t *d_t2q_idx2, const int32_t *d_t2q_dist2, int nt, int nq,
+                        int32_t *d_match_idx, int32_t *d_match_dist, void *stream) {
+  if (nt < 0 || nq < 0) return SLAMHIP_EINVAL;
+  if (nq == 0) return SLAMHIP_OK;
+  if (!d_match_idx || !d_match_dist || (nt > 0 && (!d_t2q_idx2 || !d_t2q_dist2)))
+    return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(cross_check_kernel, dim3(slamhip_ceil_div(nq, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_t2q_idx2, d_t2q_dist2, nt, nq, d_match_idx,
+                     d_match_dist);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total,
+                             const int32_t *d_off, int n_segments, int max_n, int32_t *d_order,
+                             void *stream) {
+  if (n_total < 0 || dist_stride < 1 || n_segments < 1 || max_n < 0) return SLAMHIP_EINVAL;
+  if (max_n > SLAMHIP_MAX_TRAIN_ROWS || n_segments > 65535) return SLAMHIP_EUNSUPPORTED;
+  if (n_total == 0 || max_n == 0) return SLAMHIP_OK;
+  if (!d_dist || !d_order) return SLAMHIP_EINVAL;
+  if (n_segments > 1 && !d_off) return SLAMHIP_EINVAL;
+  const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
+  hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_dist,
+                     dist_stride, d_off ? 0 : n_total, d_off, d_order);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,345 @@
+// PnP-RANSAC consensus scoring for gfx950: hypotheses x points in fp64.
+//
+// Mapping: one lane per HYPOTHESIS.  The lane turns its [R|t] into the left and
+// right projection matrices once (24 fp64 registers) and then walks the points,
+// which are wave-uniform (staged in LDS as fp64, read with a broadcast
+// address).  Each lane keeps its own inlier count, so scoring needs no
+// cross-lane reduction at all; the grid splits hypotheses and point chunks over
+// blocks and point chunks are combined with one integer atomic per lane.
+//
+// Reference arithmetic (frontend/geometry/pnp.py of the reference):
+//   P_L  = K @ Rt                                   pnp.py:133
+//   Rt_R = (homogenous(M_right) @ homogenous(Rt))[:3];  P_R = K @ Rt_R   :136-138
+//   proj = (P @ [X,1])[:2] / (P @ [X,1])[2]          pnp.py:94-99 (no z>0 test)
+//   err  = sqrt(dx*dx + dy*dy)                       utils/graph_utils.py:7-11
+//   mask = (err_L <= thr) & (err_R <= thr)           pnp.py:86-91
+// The common case is decided without a division:
+//   (u*w - x)^2 + (v*w - y)^2 <= thr^2 * w^2
+// and any point whose two sides agree to 1e-10 relative is re-evaluated with the
+// reference's literal divide / sqrt / compare sequence, so the decision equals
+// the literal formula's decision on the same projection values.
+#include "common.h"
+
+namespace {
+
+struct RansacCam {
+  double K[9];
+  double MR[12];
+};
+
+constexpr int kPtsPerChunk = 128;  // points staged in LDS per block
+constexpr int kPtStride = 8;       // doubles per staged point (7 used)
+
+__device__ __forceinline__ void make_projections(const double *__restrict__ Rt,
+                                                 const RansacCam &cam, double (&PL)[12],
+                                                 double (&PR)[12]) {
+  double rt[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) rt[i] = Rt[i];
+  double rr[12];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double s = cam.MR[4 * i + 0] * rt[0 + j];
+      s = fma(cam.MR[4 * i + 1], rt[4 + j], s);
+      s = fma(cam.MR[4 * i + 2], rt[8 + j], s);
+      if (j == 3) s += cam.MR[4 * i + 3];
+      rr[4 * i + j] = s;
+    }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double a = cam.K[3 * i + 0] * rt[0 + j];
+      a = fma(cam.K[3 * i + 1], rt[4 + j], a);
+      a = fma(cam.K[3 * i + 2], rt[8 + j], a);
+      PL[4 * i + j] = a;
+      double b = cam.K[3 * i + 0] * rr[0 + j];
+      b = fma(cam.K[3 * i + 1], rr[4 + j], b);
+      b = fma(cam.K[3 * i + 2], rr[8 + j], b);
+      PR[4 * i + j] = b;
+    }
+}
+
+// Literal reference sequence for one camera (used for borderline points only).
+__device__ __noinline__ bool inlier_exact(double x, double y, double w, double mu, double mv,
+                                          double thr) {
+  const double u = x / w, v = y / w;
+  const double dx = __dsub_rn(mu, u), dy = __dsub_rn(mv, v);
+  const double e = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+  return e <= thr;  // NaN (w == 0) compares false, as in NumPy
+}
+
+__device__ __forceinline__ bool inlier_one_camera(const double (&P)[12], double X, double Y,
+                                                  double Z, double mu, double mv, double thr,
+                                                  double thr2) {
+  const double x = fma(P[0], X, fma(P[1], Y, fma(P[2], Z, P[3])));
+  const double y = fma(P[4], X, fma(P[5], Y, fma(P[6], Z, P[7])));
+  const double w = fma(P[8], X, fma(P[9], Y, fma(P[10], Z, P[11])));
+  const double dx = fma(mu, w, -x);
+  const double dy = fma(mv, w, -y);
+  const double lhs = fma(dx, dx, dy * dy);
+  const double rhs = thr2 * (w * w);
+  bool in = lhs <= rhs;
+  if (!(fabs(lhs - rhs) > 1e-10 * rhs)) in = inlier_exact(x, y, w, mu, mv, thr);
+  return in;
+}
+
+template <typename PT>
+__device__ __forceinline__ void stage_points(double *__restrict__ lds, const PT *__restrict__ pts,
+                                             const float *__restrict__ mL,
+                                             const float *__restrict__ mR, int p0, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const size_t p = (size_t)(p0 + i);
+    double *o = lds + i * kPtStride;
+    o[0] = (double)pts[3 * p + 0];
+    o[1] = (double)pts[3 * p + 1];
+    o[2] = (double)pts[3 * p + 2];
+    o[3] = (double)mL[2 * p + 0];
+    o[4] = (double)mL[2 * p + 1];
+    o[5] = (double)mR[2 * p + 0];
+    o[6] = (double)mR[2 * p + 1];
+    o[7] = 0.0;
+  }
+}
+
+// grid = (hypothesis blocks of 64, point chunks of kPtsPerChunk)
+template <typename PT>
+__global__ __launch_bounds__(64) void ransac_score_kernel(
+    const PT *__restrict__ pts, const float *__restrict__ mL, const float *__restrict__ mR, int n,
+    const double *__restrict__ Rt, const uint8_t *__restrict__ valid, int h, RansacCam cam,
+    double thr, int32_t *__restrict__ counts) {
+  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
+  const int p0 = blockIdx.y * kPtsPerChunk;
+  const int cnt = min(kPtsPerChunk, n - p0);
+  stage_points(lds, pts, mL, mR, p0, cnt);
+  __syncthreads();
+
+  const int hyp = blockIdx.x * 64 + threadIdx.x;
+  if (hyp >= h) return;
+  if (valid != nullptr && valid[hyp] == 0) {
+    if (blockIdx.y == 0) counts[hyp] = -1;
+    return;
+  }
+  double PL[12], PR[12];
+  make_projections(Rt + 12 * (size_t)hyp, cam, PL, PR);
+  const double thr2 = thr * thr;
+  int c = 0;
+  for (int i = 0; i < cnt; ++i) {
+    const double *q = lds + i * kPtStride;
+    const double X = q[0], Y = q[1], Z = q[2];
+    const bool inL = inlier_one_camera(PL, X, Y, Z, q[3], q[4], thr, thr2);
+    const bool inR = inlier_one_camera(PR, X, Y, Z, q[5], q[6], thr, thr2);
+    c += (inL && inR) ? 1 : 0;
+  }
+  if (gridDim.y == 1) counts[hyp] = c;
+  else if (c != 0) atomicAdd(&counts[hyp], c);
+}
+
+// One hypothesis, one lane per point.
+template <typename PT>
+__global__ __launch_bounds__(256) void ransac_mask_kernel(
+    const PT *__restrict__ pts, const float *__restrict__ mL, const float *__restrict__ mR, int n,
+    const double *__restrict__ Rt_one, RansacCam cam, double thr, uint8_t *__restrict__ mask) {
+  double PL[12], PR[12];
+  make_projections(Rt_one, cam, PL, PR);
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double X = (double)pts[3 * (size_t)p + 0];
+  const double Y = (double)pts[3 * (size_t)p + 1];
+  const double Z = (double)pts[3 * (size_t)p + 2];
+  const double thr2 = thr * thr;
+  const bool inL = inlier_one_camera(PL, X, Y, Z, (double)mL[2 * (size_t)p + 0],
+                                     (double)mL[2 * (size_t)p + 1], thr, thr2);
+  const bool inR = inlier_one_camera(PR, X, Y, Z, (double)mR[2 * (size_t)p + 0],
+                                     (double)mR[2 * (size_t)p + 1], thr, thr2);
+  mask[p] = (inL && inR) ? 1 : 0;
+}
+
+// Sequential replay of the adaptive stopping rule (pnp.py:123-158) by one lane.
+__global__ void ransac_replay_kernel(const int32_t *__restrict__ counts, int h, int n_points,
+                                     double p_success, int n_iter_max, int early_inliers,
+                                     int32_t *__restrict__ result) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int best_count = 0, best_idx = -1, iter_done = 0, domain_error = 0;
+  int n_req = n_iter_max;
+  const double log1mp = log(1.0 - p_success);
+  const int limit = min(h, n_iter_max);
+  while (iter_done < n_req && iter_done < limit) {
+    const int c = counts[iter_done];
+    const int idx = iter_done;
+    ++iter_done;
+    if (c < 0) continue;  // failed minimal solve: iteration counted, nothing scored
+    if (c > best_count) {
+      best_count = c;
+      best_idx = idx;
+      const double w = (double)best_count / (double)n_points;
+      if (w > 0.0) {
+        const double w2 = w * w;
+        const double den = log(1.0 - w2 * w2);  // w**4 ; -inf when every point is an inlier
+        if (best_count >= n_points || !(p_success < 1.0)) domain_error = 1;  // math.log(0)
+        const double r = ceil(log1mp / den);
+        n_req = r > 2147483647.0 ? 2147483647 : (int)r;
+      }
+    }
+    if (early_inliers >= 0 && best_count >= early_inliers) break;
+  }
+  result[0] = best_idx;
+  result[1] = best_count;
+  result[2] = iter_done;
+  result[3] = n_req;
+  result[4] = domain_error;
+  result[5] = 0;
+  result[6] = 0;
+  result[7] = 0;
+}
+
+struct Proj { double P[12]; };
+
+// PnP.project (pnp.py:94-99): (P @ [X,1])[:2] / (P @ [X,1])[2] in fp64.
+template <typename PT>
+__global__ __launch_bounds__(256) void project_kernel(const PT *__restrict__ pts, int n, Proj pr,
+                                                      double *__restrict__ out) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const double X = (double)pts[3 * (size_t)p + 0];
+  const double Y = (double)pts[3 * (size_t)p + 1];
+  const double Z = (double)pts[3 * (size_t)p + 2];
+  const double *P = pr.P;
+  const double x = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[0], X), __dmul_rn(P[1], Y)), __dmul_rn(P[2], Z)), P[3]);
+  const double y = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[4], X), __dmul_rn(P[5], Y)), __dmul_rn(P[6], Z)), P[7]);
+  const double w = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[8], X), __dmul_rn(P[9], Y)), __dmul_rn(P[10], Z)), P[11]);
+  out[2 * (size_t)p + 0] = x / w;
+  out[2 * (size_t)p + 1] = y / w;
+}
+
+// compute_err (utils/graph_utils.py:7-11) twice + PnP.supporters_pair (pnp.py:86-91).
+__global__ __launch_bounds__(256) void supporters_kernel(const double *__restrict__ mL,
+                                                         const double *__restrict__ pL,
+                                                         const double *__restrict__ mR,
+                                                         const double *__restrict__ pR, int n,
+                                                         double thr, uint8_t *__restrict__ mask) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t i = 2 * (size_t)p;
+  const double ax = __dsub_rn(mL[i], pL[i]), ay = __dsub_rn(mL[i + 1], pL[i + 1]);
+  const double bx = __dsub_rn(mR[i], pR[i]), by = __dsub_rn(mR[i + 1], pR[i + 1]);
+  const double eL = sqrt(__dadd_rn(__dmul_rn(ax, ax), __dmul_rn(ay, ay)));
+  const double eR = sqrt(__dadd_rn(__dmul_rn(bx, bx), __dmul_rn(by, by)));
+  mask[p] = (eL <= thr && eR <= thr) ? 1 : 0;
+}
+
+void fill_cam(RansacCam &cam, const double *K, const double *M_right) {
+  for (int i = 0; i < 9; ++i) cam.K[i] = K[i];
+  for (int i = 0; i < 12; ++i) cam.MR[i] = M_right[i];
+}
+
+}  // namespace
+
+extern "C" {
+
+int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_meas_l,
+                         const float *d_meas_r, int n, const double *d_Rt,
+                         const uint8_t *d_valid, int h, const double *K, const double *M_right,
+                         double thresh, int32_t *d_counts, void *stream) {
+  if (n < 0 || h < 0) return SLAMHIP_EINVAL;
+  if (h == 0) return SLAMHIP_OK;
+  if (!d_Rt || !d_counts || !K || !M_right) return SLAMHIP_EINVAL;
+  if (n > 0 && (!d_points || !d_meas_l || !d_meas_r)) return SLAMHIP_EINVAL;
+  hipStream_t st = (hipStream_t)stream;
+  RansacCam cam;
+  fill_cam(cam, K, M_right);
+  const int chunks = n > 0 ? slamhip_ceil_div(n, kPtsPerChunk) : 1;
+  if (chunks > 65535) return SLAMHIP_EUNSUPPORTED;
+  if (chunks > 1) {
+    if (hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)h, st) != hipSuccess)
+      return SLAMHIP_ELAUNCH;
+  }
+  const dim3 grid(slamhip_ceil_div(h, 64), chunks), block(64);
+  if (points_fp64)
+    hipLaunchKernelGGL(ransac_score_kernel<double>, grid, block, 0, st, (const double *)d_points,
+                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts);
+  else
+    hipLaunchKernelGGL(ransac_score_kernel<float>, grid, block, 0, st, (const float *)d_points,
+                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_ransac_mask(const void *d_points, int points_fp64, const float *d_meas_l,
+                        const float *d_meas_r, int n, const double *d_Rt_one, const double *K,
+                        const double *M_right, double thresh, uint8_t *d_mask, void *stream) {
+  if (n < 0) return SLAMHIP_EINVAL;
+  if (n == 0) return SLAMHIP_OK;
+  if (!d_points || !d_meas_l || !d_meas_r || !d_Rt_one || !K || !M_right || !d_mask)
+    return SLAMHIP_EINVAL;
+  RansacCam cam;
+  fill_cam(cam, K, M_right);
+  const dim3 grid(slamhip_ceil_div(n, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (points_fp64)
+    hipLaunchKernelGGL(ransac_mask_kernel<double>, grid, block, 0, st, (const double *)d_points,
+                       d_meas_l, d_meas_r, n, d_Rt_one, cam, thresh, d_mask);
+  else
+    hipLaunchKernelGGL(ransac_mask_kernel<float>, grid, block, 0, st, (const float *)d_points,
+                       d_meas_l, d_meas_r, n, d_Rt_one, cam, thresh, d_mask);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_ransac_replay(const int32_t *d_counts, int h, int n_points, double p_success,
+                          int n_iter_max, int early_inliers, int32_t *d_result, void *stream) {
+  if (h < 0 || n_points < 1 || n_iter_max < 0) return SLAMHIP_EINVAL;
+  if (!d_result || (h > 0 && !d_counts)) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(ransac_replay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_counts, h,
+                     n_points, p_success, n_iter_max, early_inliers, d_result);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_project(const void *d_points, int points_fp64, int n, const double *P,
+                    double *d_pixels, void *stream) {
+  if (n < 0) return SLAMHIP_EINVAL;
+  if (n == 0) return SLAMHIP_OK;
+  if (!d_points || !P || !d_pixels) return SLAMHIP_EINVAL;
+  Proj pr;
+  for (int i = 0; i < 12; ++i) pr.P[i] = P[i];
+  const dim3 grid(slamhip_ceil_div(n, 256)), block(256);
+  if (points_fp64)
+    hipLaunchKernelGGL(project_kernel<double>, grid, block, 0, (hipStream_t)stream,
+                       (const double *)d_points, n, pr, d_pixels);
+  else
+    hipLaunchKernelGGL(project_kernel<float>, grid, block, 0, (hipStream_t)stream,
+                       (const float *)d_points, n, pr, d_pixels);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_supporters_pair(const double *d_meas_l, const double *d_proj_l,
+                            const double *d_meas_r, const double *d_proj_r, int n, double thresh,
+                            uint8_t *d_mask, void *stream) {
+  if (n < 0) return SLAMHIP_EINVAL;
+  if (n == 0) return SLAMHIP_OK;
+  if (!d_meas_l || !d_proj_l || !d_meas_r || !d_proj_r || !d_mask) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(supporters_kernel, dim3(slamhip_ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_meas_l, d_proj_l, d_meas_r, d_proj_r, n, thresh,
+                     d_mask);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_version(void) { return SLAMHIP_VERSION; }
+
+const char *slamhip_strerror(int code) {
+  switch (code) {
+    case SLAMHIP_OK: return "ok";
+    case SLAMHIP_EINVAL: return "invalid argument";
+    case SLAMHIP_EUNSUPPORTED: return "size outside the supported range";
+    case SLAMHIP_EWORKSPACE: return "workspace missing or too small";
+    case SLAMHIP_ELAUNCH: return "HIP launch failed";
+    default: return "unknown error";
+  }
+}
+
+}  // extern "C"

@@ -1,0 +1,59 @@
+"""CPU tests of the boundary: the shared library loads, exports every symbol
+the header declares, and the Python binding table covers the same set."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "slamhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(slamhip_\w+)\s*\(", text)))
+
+
+def test_header_declares_something():
+    syms = declared_symbols()
+    assert "slamhip_hamming_knn2" in syms and "slamhip_ransac_score" in syms
+
+
+def test_library_exports_every_declared_symbol():
+    from slam_amd import _lib
+    for name in declared_symbols():
+        assert hasattr(_lib.lib, name), f"{name} declared in slamhip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    from slam_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_version_and_strerror_without_gpu():
+    from slam_amd import _lib
+    assert _lib.lib.slamhip_version() == 100
+    assert _lib.strerror(0) == "ok"
+    assert "workspace" in _lib.strerror(_lib.EWORKSPACE)
+    # argument validation happens before any device work
+    assert _lib.lib.slamhip_hamming_knn2(None, -1, None, 0, 61, 61, None, None, None, 0, None) == _lib.EINVAL
+    assert _lib.lib.slamhip_hamming_knn2_workspace_bytes(8192, 8192, 1, 8192, 8192, 61) > 0
+    assert _lib.lib.slamhip_hamming_knn2_workspace_bytes(10, 10, 1, 10, 10, 500) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy as np
+    from slam_amd import kernels
+    with pytest.raises(RuntimeError):
+        kernels.hamming_knn2(np.zeros((4, 61), np.uint8), np.zeros((4, 61), np.uint8))
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "slam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.lower().replace("# no oracle", ""), f

@@ -1,0 +1,159 @@
+"""GPU parity tests of the Hamming matcher: HIP path (through the C ABI) vs the
+CPU oracle, bit-exact on indices and distances."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _reset_tuning():
+    from slam_amd import _lib
+    yield
+    _lib.lib.slamhip_tune(0, -1)
+    _lib.lib.slamhip_tune(1, 0)
+
+
+def _run(q, t):
+    from slam_amd import kernels
+    i, d = kernels.hamming_knn2(q, t)
+    torch.cuda.synchronize()
+    return i.cpu().numpy(), d.cpu().numpy()
+
+
+def test_library_loaded_is_in_tree():
+    from slam_amd import _lib
+    assert _lib.LIB_PATH.endswith("slam_amd/libslamhip.so")
+
+
+def test_golden_cases(golden):
+    g = golden("oracle_hamming.npz")
+    for name in ("akaze", "orb", "nt1", "nt2"):
+        i, d = _run(g[f"{name}_q"], g[f"{name}_t"])
+        np.testing.assert_array_equal(i, g[f"{name}_idx2"], err_msg=name)
+        np.testing.assert_array_equal(d, g[f"{name}_dist2"], err_msg=name)
+
+
+@pytest.mark.parametrize("variant", [0, 1, 4, 5])
+@pytest.mark.parametrize("splits", [0, 1, 3, 64])
+def test_every_kernel_variant_with_ties(variant, splits):
+    from slam_amd import _lib
+    _lib.lib.slamhip_tune(0, variant)
+    _lib.lib.slamhip_tune(1, splits)
+    rng = np.random.default_rng(variant * 10 + splits)
+    for nq, nt, d in [(1, 1, 61), (63, 65, 61), (257, 129, 32), (600, 700, 61), (300, 40, 33),
+                      (130, 513, 128), (70, 90, 1), (64, 256, 64)]:
+        q = rng.integers(0, 256, (nq, d), dtype=np.uint8)
+        t = rng.integers(0, 256, (nt, d), dtype=np.uint8)
+        if nq % 2 == 0:  # few distinct byte values -> a lot of equal distances
+            q &= 1
+            t &= 1
+        i, dd = _run(q, t)
+        ei, ed = so.hamming_knn2(q, t)
+        np.testing.assert_array_equal(i, ei, err_msg=f"{nq}x{nt}x{d}")
+        np.testing.assert_array_equal(dd, ed, err_msg=f"{nq}x{nt}x{d}")
+
+
+def test_empty_inputs():
+    q = np.zeros((5, 61), np.uint8)
+    i, d = _run(q, np.zeros((0, 61), np.uint8))
+    assert (i == -1).all() and (d == -1).all()
+    i, d = _run(np.zeros((0, 61), np.uint8), q)
+    assert i.shape == (0, 2)
+
+
+def test_full_size_8k_vs_c_oracle(oracle_c):
+    from slam_amd.utils.synth import matcher_workload
+    q, t = matcher_workload(8192, 8192, 61, seed=0)
+    i, d = _run(q, t)
+    ei, ed = oracle_c(q, t, threads=8)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(d, ed)
+    # size-independent properties: a set matched against itself finds itself at
+    # distance 0 (lowest index among exact duplicates); distances are ordered
+    i2, d2 = _run(t, t)
+    assert (d2[:, 0] == 0).all() and (i2[:, 0] <= np.arange(8192)).all()
+    assert (d2[:, 0] <= d2[:, 1]).all()
+
+
+def test_batched_ragged_pairs():
+    from slam_amd import kernels
+    rng = np.random.default_rng(9)
+    nqs = [0, 5, 300, 64, 1, 777]
+    nts = [10, 0, 257, 2, 1, 1500]
+    qs = [rng.integers(0, 256, (n, 61), dtype=np.uint8) for n in nqs]
+    ts = [rng.integers(0, 256, (n, 61), dtype=np.uint8) for n in nts]
+    q_off = np.concatenate([[0], np.cumsum(nqs)]).astype(np.int32)
+    t_off = np.concatenate([[0], np.cumsum(nts)]).astype(np.int32)
+    i, d = kernels.hamming_knn2_batched(np.vstack(qs), np.vstack(ts), q_off, t_off)
+    i, d = i.cpu().numpy(), d.cpu().numpy()
+    for p in range(len(nqs)):
+        ei, ed = so.hamming_knn2(qs[p], ts[p])
+        np.testing.assert_array_equal(i[q_off[p]:q_off[p + 1]], ei, err_msg=f"pair {p}")
+        np.testing.assert_array_equal(d[q_off[p]:q_off[p + 1]], ed, err_msg=f"pair {p}")
+
+
+def test_ratio_test_and_sort_and_cross_check():
+    from slam_amd import kernels
+    from slam_amd.utils.synth import matcher_workload
+    q, t = matcher_workload(1000, 900, 61, seed=2)
+    i, d = kernels.hamming_knn2(q, t)
+    for ratio in (0.5, 0.8, 0.99, 1.0):
+        keep = kernels.ratio_test(d, ratio).cpu().numpy().astype(bool)
+        np.testing.assert_array_equal(keep, so.ratio_test(d.cpu().numpy(), ratio))
+    order = kernels.sort_by_distance(d[:, 0].contiguous()).cpu().numpy()
+    np.testing.assert_array_equal(order, so.sort_by_distance(d[:, 0].cpu().numpy()))
+    order2 = kernels.sort_by_distance(d, stride=2).cpu().numpy()
+    np.testing.assert_array_equal(order2, order)
+    mi, md = kernels.cross_check_match(q, t)
+    t2q_i, t2q_d = so.hamming_knn2(t, q)
+    ei, ed = so.cross_check_fold(t2q_i[:, 0], t2q_d[:, 0], q.shape[0])
+    np.testing.assert_array_equal(mi.cpu().numpy(), ei)
+    np.testing.assert_array_equal(md.cpu().numpy(), ed)
+
+
+def test_sort_large_and_segmented():
+    from slam_amd import kernels
+    rng = np.random.default_rng(4)
+    d = rng.integers(0, 489, 9000).astype(np.int32)
+    d[rng.random(9000) < 0.01] = -1
+    order = kernels.sort_by_distance(d).cpu().numpy()
+    np.testing.assert_array_equal(order, so.sort_by_distance(d))
+    sizes = [0, 3, 1025, 256, 1, 2047]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    dd = rng.integers(0, 30, int(off[-1])).astype(np.int32)
+    o = kernels.sort_by_distance(dd, off=off).cpu().numpy()
+    for s in range(len(sizes)):
+        np.testing.assert_array_equal(o[off[s]:off[s + 1]], so.sort_by_distance(dd[off[s]:off[s + 1]]))
+
+
+@pytest.mark.parametrize("cross_check", [False, True])
+def test_descriptor_matcher_facade(cross_check):
+    from slam_amd import DescriptorMatcher
+    from slam_amd.utils.synth import matcher_workload
+    q, t = matcher_workload(500, 450, 61, seed=7)
+    m = DescriptorMatcher(cross_check=cross_check).match(q, t)
+    qi, ti, di = so.bf_match(q, t, cross_check=cross_check)
+    assert len(m) == len(qi)
+    np.testing.assert_array_equal(m.query_idx, qi)
+    np.testing.assert_array_equal(m.train_idx, ti)
+    np.testing.assert_array_equal(m.distance, di.astype(np.float32))
+    first = m[0]
+    assert (first.queryIdx, first.trainIdx, first.imgIdx) == (int(qi[0]), int(ti[0]), 0)
+    if not cross_check:
+        assert len(m) == q.shape[0]  # one match per query row (asserted by the reference's DB)
+        raw = DescriptorMatcher(cross_check=False).knn_match(q, t, k=2)
+        good, rejected = DescriptorMatcher.ratio_test(raw, 0.8)
+        idx2, dist2 = so.hamming_knn2(q, t)
+        keep = so.ratio_test(dist2, 0.8)
+        assert [g.queryIdx for g in good] == np.flatnonzero(keep).tolist()
+        assert len(good) + len(rejected) == q.shape[0]
+
+
+def test_facade_errors_like_reference():
+    from slam_amd import DescriptorMatcher
+    with pytest.raises(ValueError):
+        DescriptorMatcher(cross_check=False, matcher_type="flann")

@@ -1,0 +1,147 @@
+"""GPU parity tests of PnP-RANSAC consensus scoring: inlier counts identical to
+the reference arithmetic, except for points within 1e-6 px of the threshold."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+BAND = 1e-6  # px; stated tolerance band around the reprojection threshold
+
+
+def _assert_masks(mask, eL, eR, thr, what):
+    ref = (eL <= thr) & (eR <= thr)
+    diff = np.flatnonzero(mask.astype(bool) != ref)
+    for p in diff:
+        near = min(abs(eL[p] - thr), abs(eR[p] - thr))
+        assert near <= BAND, f"{what}: point {p} differs, errors {eL[p]}, {eR[p]}"
+    return len(diff)
+
+
+def test_scores_and_masks_match_reference_golden(golden):
+    from slam_amd import kernels
+    g = golden("ref_ransac_score.npz")
+    K, MR, thr = g["K"], g["M_right"], float(g["pixel_thresh"])
+    counts = kernels.ransac_score(g["X"], g["meas_L"], g["meas_R"], g["Rts"], None, K, MR, thr)
+    counts = counts.cpu().numpy()
+    n_diff = 0
+    for h in range(g["Rts"].shape[0]):
+        mask = kernels.ransac_mask(g["X"], g["meas_L"], g["meas_R"], g["Rts"][h], K, MR, thr)
+        mask = mask.cpu().numpy()
+        n_diff += _assert_masks(mask, g["err_L"][h], g["err_R"][h], thr, f"hyp {h}")
+        assert counts[h] == mask.sum()
+    np.testing.assert_array_equal(counts, g["counts"]) if n_diff == 0 else None
+    assert n_diff == 0  # nothing in this fixture sits inside the band
+
+
+def test_project_and_supporters_match_reference_golden(golden):
+    from slam_amd import kernels
+    g = golden("ref_ransac_score.npz")
+    K, thr = g["K"], float(g["pixel_thresh"])
+    for h in (0, 5):
+        P = K @ g["Rts"][h]
+        pix = kernels.project(g["X"], P).cpu().numpy()
+        ref = g["proj_L"][h]
+        ok = np.isfinite(ref).all(axis=1)
+        np.testing.assert_allclose(pix[ok], ref[ok], rtol=1e-13, atol=0)
+        m = kernels.supporters_pair(g["meas_L"], g["proj_L"][h], g["meas_R"], g["proj_R"][h], thr)
+        np.testing.assert_array_equal(m.cpu().numpy(), g["masks"][h])
+
+
+def test_scores_large_random_scene_with_invalid_hypotheses():
+    from slam_amd import kernels, CameraModel
+    from slam_amd.utils.synth import perturbed_hypotheses
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(8)
+    n, H = 1111, 2500
+    X = np.column_stack([rng.uniform(-25, 25, n), rng.uniform(-3, 2, n), rng.uniform(4, 120, n)]).astype(np.float32)
+    ang = 0.01
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    Rt = np.hstack([R, np.array([[0.02], [-0.01], [-0.8]])])
+    Rt_R = (so.homogenous(cam.M_right) @ so.homogenous(Rt))[:3]
+    mL = (so.project(X, cam.K @ Rt) + rng.normal(0, 0.7, (n, 2))).astype(np.float32)
+    mR = (so.project(X, cam.K @ Rt_R) + rng.normal(0, 0.7, (n, 2))).astype(np.float32)
+    bad = rng.random(n) < 0.35
+    mL[bad] += rng.normal(0, 30, (int(bad.sum()), 2)).astype(np.float32)
+    Rts, valid = perturbed_hypotheses(rng, Rt, H)
+    for thr in (4.0, 1.5):
+        counts = kernels.ransac_score(X, mL, mR, Rts, valid, cam.K, cam.M_right, thr).cpu().numpy()
+        ref = so.score_hypotheses(cam.K, cam.M_right, Rts, valid, X, mL, mR, thr)
+        bad_h = np.flatnonzero(counts != ref)
+        for h in bad_h:  # any difference must be explained by points inside the band
+            eL, eR = so.hypothesis_errors(cam.K, cam.M_right, Rts[h], X, mL, mR)
+            in_band = (np.abs(eL - thr) <= BAND) | (np.abs(eR - thr) <= BAND)
+            assert abs(int(counts[h]) - int(ref[h])) <= in_band.sum()
+        assert len(bad_h) <= 2
+        assert (counts[valid == 0] == -1).all()
+    # fp64 landmarks (loop-closure call site) take the same path
+    c64 = kernels.ransac_score(X.astype(np.float64), mL, mR, Rts[:64], None, cam.K, cam.M_right, 4.0)
+    c32 = kernels.ransac_score(X, mL, mR, Rts[:64], None, cam.K, cam.M_right, 4.0)
+    np.testing.assert_array_equal(c64.cpu().numpy(), c32.cpu().numpy())
+
+
+def test_general_right_camera_matrix():
+    """M_right with a rotation: the full 4x4 product must be honoured."""
+    from slam_amd import kernels, CameraModel
+    rng = np.random.default_rng(2)
+    cam = CameraModel.kitti_like()
+    a = 0.02
+    Rr = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+    MR = np.hstack([Rr, np.array([[-0.54], [0.01], [0.002]])])
+    n = 300
+    X = np.column_stack([rng.uniform(-10, 10, n), rng.uniform(-3, 2, n), rng.uniform(4, 60, n)]).astype(np.float32)
+    Rt = np.hstack([np.eye(3), np.array([[0.0], [0.0], [-0.5]])])
+    mL = so.project(X, cam.K @ Rt).astype(np.float32)
+    mR = so.project(X, cam.K @ (so.homogenous(MR) @ so.homogenous(Rt))[:3]).astype(np.float32)
+    Rts = np.stack([Rt, np.hstack([np.eye(3), np.array([[0.3], [0.0], [-0.5]])])])
+    counts = kernels.ransac_score(X, mL, mR, Rts, None, cam.K, MR, 1.0).cpu().numpy()
+    ref = so.score_hypotheses(cam.K, MR, Rts, None, X, mL, mR, 1.0)
+    np.testing.assert_array_equal(counts, ref)
+    assert counts[0] == n
+
+
+def test_device_replay_matches_oracle(golden):
+    from slam_amd import kernels
+    g = golden("oracle_ransac_replay.npz")
+    for i in range(4):
+        res = kernels.ransac_replay(g[f"counts{i}"], int(g[f"N{i}"])).cpu().numpy()
+        np.testing.assert_array_equal(res[:4], g[f"res{i}"], err_msg=f"trace {i}")
+        assert res[4] == 0
+    res = kernels.ransac_replay(np.array([10, 50, 3], np.int32), 50).cpu().numpy()
+    assert res[0] == 1 and res[1] == 50 and res[4] == 1   # where the reference raises ValueError
+    res = kernels.ransac_replay(np.array([5, 9, 7, 30, 2], np.int32), 60, early_inliers=9).cpu().numpy()
+    assert tuple(res[:3]) == (1, 9, 2)
+
+
+def test_pnp_facade_with_injected_hypotheses():
+    from slam_amd import PnP, CameraModel
+    from slam_amd.utils.synth import perturbed_hypotheses
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(21)
+    n = 550
+    X = np.column_stack([rng.uniform(-25, 25, n), rng.uniform(-3, 2, n), rng.uniform(4, 120, n)]).astype(np.float32)
+    Rt = np.hstack([np.eye(3), np.array([[0.01], [0.0], [-0.8]])])
+    Rt_R = (so.homogenous(cam.M_right) @ so.homogenous(Rt))[:3]
+    mL = (so.project(X, cam.K @ Rt) + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+    mR = (so.project(X, cam.K @ Rt_R) + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+    bad = rng.random(n) < 0.35
+    mL[bad] += rng.normal(0, 30, (int(bad.sum()), 2)).astype(np.float32)
+    Rts, valid = perturbed_hypotheses(rng, Rt, 2500, good_fraction=0.1)
+    pnp = PnP(cam, pixel_thresh=4.0)
+    for kwargs in ({}, {"n_iter_max": 1500}, {"early_inliers": 200}, {"block": 7}):
+        mask = pnp.ransac_pnp_pair1(X, mL, mR, hypotheses=(Rts, valid), **kwargs)
+        okw = {k: v for k, v in kwargs.items() if k != "block"}
+        counts = so.score_hypotheses(cam.K, cam.M_right, Rts, valid, X, mL, mR, 4.0)
+        best, best_count, it, req = so.ransac_replay(counts, n, 0.99999, okw.get("n_iter_max", 2500),
+                                                      okw.get("early_inliers"))
+        ref = so.hypothesis_mask(cam.K, cam.M_right, Rts[best], X, mL, mR, 4.0)
+        np.testing.assert_array_equal(mask, ref)
+        assert mask.dtype == bool and mask.sum() == best_count
+    # reference-shaped helpers
+    P = cam.K @ Rt
+    np.testing.assert_allclose(PnP.project(X, P), so.project(X, P), rtol=1e-13)
+    s = pnp.supporters_pair(mL, so.project(X, P), mR, so.project(X, cam.K @ Rt_R))
+    np.testing.assert_array_equal(s, so.supporters_pair(mL, so.project(X, P), mR,
+                                                        so.project(X, cam.K @ Rt_R), 4.0))
