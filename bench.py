@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Benchmark of the front-end hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): brute-force Hamming kNN (k=2) + ratio test
+of 8192 x 8192 AKAZE-shaped 61-byte descriptors, inputs resident in HBM.  One
+step = one full matcher call (row packing, top-2 kernel, split merge, ratio
+test).  With N > 1 every rank (one process per GPU, RCCL only for the barrier
+and the max-over-ranks of the time) matches its own independent descriptor
+pair: pairs shard with no data-path collective, so scaling is weak.
+
+Prints ONE JSON line on rank 0.  `value` = Hamming compares per second over all
+ranks.  `roofline` prices the dominant kernel (hamming_top2_kernel) in int32
+VALU lane-operations: 2*ceil(D/4) = 32 per compare (16 v_xor_b32 + 16
+v_bcnt_u32_b32), against 4 SIMD x 32 lanes x 256 CU x 2.4 GHz = 78.6 Tlane-op/s.
+`cpu_baseline` times the C/OpenMP restatement (oracle/hamming_oracle.c) of the
+same workload on the host cores of this machine.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+NQ = NT = 8192
+DESC_BYTES = 61
+RATIO = 0.8
+PEAK_LANE_OPS = 4 * 32 * 256 * 2.4e9      # int32 VALU lane-ops/s (MI355X, 2-cycle wave64 issue)
+OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
+HBM_BYTES_PER_CALL = (NQ + NT) * DESC_BYTES + NQ * 16 + NQ   # read descriptors, write idx2/dist2/keep
+
+
+def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 1.5):
+    """Times the CPU port (C + OpenMP, all host threads OpenMP gives us)."""
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    if not os.path.exists(path):
+        return None
+    lib = C.CDLL(path)
+    lib.oracle_hamming_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_hamming_knn2.restype = None
+    lib.oracle_max_threads.restype = C.c_int
+    threads = int(lib.oracle_max_threads())
+    idx2 = np.empty((q.shape[0], 2), np.int32)
+    dist2 = np.empty((q.shape[0], 2), np.int32)
+
+    def once():
+        lib.oracle_hamming_knn2(q.ctypes.data, q.shape[0], t.ctypes.data, t.shape[0], q.shape[1],
+                                q.shape[1], idx2.ctypes.data, dist2.ctypes.data, 0)
+    once()  # warm
+    t0 = time.perf_counter()
+    once()
+    one = time.perf_counter() - t0
+    reps = max(1, min(50, int(target_s / max(one, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        once()
+    dt = time.perf_counter() - t0
+    return {
+        "value": q.shape[0] * t.shape[0] * reps / dt,
+        "unit": "hamming_compares/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{reps} x full {q.shape[0]}x{t.shape[0]}x{q.shape[1]}B kNN(k=2), "
+                  f"oracle/hamming_oracle.c (popcnt, OpenMP {threads} threads of "
+                  f"{os.cpu_count()} host CPUs), {dt:.2f} s wall; cv2 is not installed so the "
+                  f"reference's cv2.BFMatcher call itself cannot be timed",
+    }, idx2, dist2
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    from slam_amd import _lib, kernels
+    from slam_amd.utils.synth import matcher_workload
+
+    q_np, t_np = matcher_workload(NQ, NT, DESC_BYTES, seed=rank)
+    q = kernels.to_device(q_np, torch.uint8)
+    t = kernels.to_device(t_np, torch.uint8)
+
+    idx2 = torch.empty((NQ, 2), dtype=torch.int32, device=q.device)
+    dist2 = torch.empty((NQ, 2), dtype=torch.int32, device=q.device)
+    keep = torch.empty(NQ, dtype=torch.uint8, device=q.device)
+
+    def step():
+        kernels.hamming_knn2(q, t, out=(idx2, dist2))
+        kernels.ratio_test(dist2, RATIO, out=keep)
+        return idx2, dist2, keep
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # Same K steps again with the top-2 kernel bracketed by HIP events on its
+    # launch stream: average duration of the dominant kernel.  Kept out of the
+    # timed region above so the event records do not perturb `value`.
+    check = _lib.check
+    check(_lib.lib.slamhip_profile_begin(args.steps), "slamhip_profile_begin")
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    total_ms = C.c_double(0.0)
+    n_launch = _lib.lib.slamhip_profile_end(C.byref(total_ms))
+    kernel_s = (total_ms.value / max(n_launch, 1)) * 1e-3
+
+    if rank == 0:
+        compares = float(NQ) * NT
+        achieved = compares * OPS_PER_COMPARE / kernel_s
+        line = {
+            "metric": "hamming_compares_per_sec",
+            "value": compares * args.steps * world / elapsed,
+            "unit": "compares/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 (xor+popcount)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: 8192x8192 AKAZE 61-byte descriptors, "
+                                   "brute-force Hamming kNN(k=2) + ratio test, one pair per GPU",
+                       "nq": NQ, "nt": NT, "desc_bytes": DESC_BYTES, "ratio": RATIO,
+                       "parallelism": f"independent pairs x{world}"},
+            "roofline": {"bound": "valu-int32", "kernel": "hamming_top2_kernel",
+                         "achieved": achieved / 1e12, "peak": PEAK_LANE_OPS / 1e12,
+                         "unit": "Tlane-op/s", "frac": achieved / PEAK_LANE_OPS,
+                         "ops_per_compare": OPS_PER_COMPARE,
+                         "kernel_us": kernel_s * 1e6, "launches_timed": n_launch,
+                         "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res = cpu_baseline(q_np, t_np)
+            if res is not None:
+                base, ci, cd = res
+                line["cpu_baseline"] = base
+                line["gpu_vs_cpu"] = line["value"] / base["value"]
+                idx2, dist2, _ = out
+                line["parity_vs_cpu_port"] = bool((idx2.cpu().numpy() == ci).all() and
+                                                  (dist2.cpu().numpy() == cd).all())
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

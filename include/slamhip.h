@@ -53,6 +53,13 @@ const char *slamhip_strerror(int code);
  * not for use while other threads are inside the library. */
 int slamhip_tune(int knob, int value);
 
+/* Diagnostics only: kernel-duration probe.  After begin(max_launches) the
+ * matcher brackets its top-2 kernel with HIP events recorded on the launch
+ * stream.  end() waits for them, stores their summed duration (milliseconds)
+ * and returns how many launches were bracketed (negative = error). */
+int slamhip_profile_begin(int max_launches);
+int slamhip_profile_end(double *total_ms);
+
 /* ------------------------------------------------------------------------- */
 /* Hamming brute-force k=2 nearest neighbours.                               */
 /* Replaces cv2.BFMatcher(NORM_HAMMING).match / knnMatch(k=2) as called from */

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be loaded first: it brings its own HIP runtime, and the library has
+# to bind to that same runtime so that torch's device pointers and streams are
+# valid in our launches.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libslamhip.so")
 
@@ -40,6 +45,8 @@ SIGNATURES = {
     "slamhip_version": (_i, []),
     "slamhip_strerror": (C.c_char_p, [_i]),
     "slamhip_tune": (_i, [_i, _i]),
+    "slamhip_profile_begin": (_i, [_i]),
+    "slamhip_profile_end": (_i, [_dp]),
     "slamhip_hamming_knn2_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "slamhip_hamming_knn2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "slamhip_hamming_knn2_batched": (

@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "../../include/slamhip.h"
 
+// hipGetLastError() is sticky per thread: an error left behind by unrelated HIP
+// calls of the host application would otherwise be reported as ours.
+#define SLAMHIP_BEGIN() ((void)hipGetLastError())
+
 #define SLAMHIP_CHECK_LAUNCH()                         \
   do {                                                 \
     hipError_t e__ = hipGetLastError();                \

@@ -156,6 +156,7 @@ extern "C" int slamhip_stereo_filter_triangulate(const void *d_kp_left, const vo
                                                  double pix_thresh, double disp_min,
                                                  uint8_t *d_keep, void *d_xyz, int out_fp64,
                                                  void *stream) {
+  SLAMHIP_BEGIN();
   if (m < 0) return SLAMHIP_EINVAL;
   if (m == 0) return SLAMHIP_OK;
   if (!d_kp_left || !d_kp_right || !P_left || !P_right || !d_xyz) return SLAMHIP_EINVAL;

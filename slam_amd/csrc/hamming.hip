@@ -19,6 +19,8 @@
 // distances, for the best and for the second best
 // (call site: frontend/vision/descriptor_matcher.py:33 of the reference).
 #include "common.h"
+#include <utility>
+#include <vector>
 
 namespace {
 
@@ -302,6 +304,16 @@ struct MatchPlan {
   size_t off_qp, off_tp, off_part, total;
 };
 
+// Optional per-launch timing of the dominant (top-2) kernel with HIP events
+// recorded on the launch stream; used by the benchmark to get the kernel's
+// average duration inside its timed region.
+struct ProfEvents {
+  bool enabled = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+};
+ProfEvents g_prof;
+
 int g_force_variant = -1;  // diagnostics: -1 auto, bit0 = LDS, bits 1.. = Q
 int g_force_splits = 0;
 
@@ -309,8 +321,11 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
                     int desc_bytes) {
   MatchPlan p;
   p.W = slamhip_packed_words(desc_bytes);
-  p.use_lds = false;
-  p.Q = (p.W <= 16 && (long long)max_nq * n_pairs >= 4096) ? 2 : 1;
+  // Measured on MI355X (8192x8192x61 B): LDS-staged tile, one query per lane is
+  // the fastest of the four variants; the SGPR-fed variant exposes scalar-load
+  // latency, two queries per lane cost occupancy.
+  p.use_lds = true;
+  p.Q = 1;
   if (g_force_variant >= 0) {
     p.use_lds = (g_force_variant & 1) != 0;
     p.Q = (g_force_variant >> 1) == 2 && p.W <= 16 ? 2 : 1;
@@ -378,6 +393,11 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   }
 
   const dim3 grid(p.qblocks, p.splits, n_pairs);
+  std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+  if (g_prof.enabled && g_prof.used < g_prof.pool.size()) {
+    ev = &g_prof.pool[g_prof.used++];
+    hipEventRecord(ev->first, st);
+  }
   const int nqs = d_q_off ? 0 : nq_total, nts = d_q_off ? 0 : nt_total;
 #define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
   launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_t_off, nqs, nts, nq_total, part, d_idx2, \
@@ -392,6 +412,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     if (p.use_lds) SLAMHIP_DISPATCH(32, 1, true); else SLAMHIP_DISPATCH(32, 1, false);
   }
 #undef SLAMHIP_DISPATCH
+  if (ev) hipEventRecord(ev->second, st);
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.splits > 1) {
@@ -416,6 +437,39 @@ int slamhip_tune(int knob, int value) {
   return SLAMHIP_OK;
 }
 
+// Kernel-duration probe for benchmarks.  begin(max_launches): from now on the
+// matcher brackets its top-2 kernel with HIP events on the launch stream (at
+// most max_launches of them).  end(): synchronises those events, returns the
+// number of bracketed launches and their summed duration in milliseconds, and
+// switches the probe off.
+int slamhip_profile_begin(int max_launches) {
+  if (max_launches < 1 || max_launches > (1 << 20)) return SLAMHIP_EINVAL;
+  while (g_prof.pool.size() < (size_t)max_launches) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return SLAMHIP_ELAUNCH;
+    g_prof.pool.emplace_back(a, b);
+  }
+  g_prof.used = 0;
+  g_prof.enabled = true;
+  return SLAMHIP_OK;
+}
+
+int slamhip_profile_end(double *total_ms) {
+  g_prof.enabled = false;
+  double sum = 0.0;
+  for (size_t i = 0; i < g_prof.used; ++i) {
+    float ms = 0.f;
+    if (hipEventSynchronize(g_prof.pool[i].second) != hipSuccess) return SLAMHIP_ELAUNCH;
+    if (hipEventElapsedTime(&ms, g_prof.pool[i].first, g_prof.pool[i].second) != hipSuccess)
+      return SLAMHIP_ELAUNCH;
+    sum += ms;
+  }
+  if (total_ms) *total_ms = sum;
+  const int n = (int)g_prof.used;
+  g_prof.used = 0;
+  return n;
+}
+
 size_t slamhip_hamming_knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq,
                                             int max_nt, int desc_bytes) {
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || desc_bytes < 1 ||
@@ -427,6 +481,7 @@ size_t slamhip_hamming_knn2_workspace_bytes(int nq_total, int nt_total, int n_pa
 int slamhip_hamming_knn2(const uint8_t *d_query, int nq, const uint8_t *d_train, int nt,
                          int desc_bytes, int row_stride, int32_t *d_idx2, int32_t *d_dist2,
                          void *d_workspace, size_t workspace_bytes, void *stream) {
+  SLAMHIP_BEGIN();
   return run_knn2(d_query, nq, d_train, nt, desc_bytes, row_stride, nullptr, nullptr, 1, nq, nt,
                   d_idx2, d_dist2, d_workspace, workspace_bytes, stream);
 }
@@ -436,6 +491,7 @@ int slamhip_hamming_knn2_batched(const uint8_t *d_query, int nq_total, const uin
                                  const int32_t *d_q_off, const int32_t *d_t_off, int n_pairs,
                                  int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
                                  void *d_workspace, size_t workspace_bytes, void *stream) {
+  SLAMHIP_BEGIN();
   if (!d_q_off || !d_t_off) return SLAMHIP_EINVAL;
   return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
                   n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, stream);
@@ -443,6 +499,7 @@ int slamhip_hamming_knn2_batched(const uint8_t *d_query, int nq_total, const uin
 
 int slamhip_ratio_test(const int32_t *d_dist2, int nq, double ratio, uint8_t *d_keep,
                        void *stream) {
+  SLAMHIP_BEGIN();
   if (nq < 0) return SLAMHIP_EINVAL;
   if (nq == 0) return SLAMHIP_OK;
   if (!d_dist2 || !d_keep) return SLAMHIP_EINVAL;
@@ -454,6 +511,7 @@ int slamhip_ratio_test(const int32_t *d_dist2, int nq, double ratio, uint8_t *d_
 
 int slamhip_cross_check(const int32_t *d_t2q_idx2, const int32_t *d_t2q_dist2, int nt, int nq,
                         int32_t *d_match_idx, int32_t *d_match_dist, void *stream) {
+  SLAMHIP_BEGIN();
   if (nt < 0 || nq < 0) return SLAMHIP_EINVAL;
   if (nq == 0) return SLAMHIP_OK;
   if (!d_match_idx || !d_match_dist || (nt > 0 && (!d_t2q_idx2 || !d_t2q_dist2)))
@@ -468,6 +526,7 @@ int slamhip_cross_check(const int32_t *d_t2q_idx2, const int32_t *d_t2q_dist2, i
 int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total,
                              const int32_t *d_off, int n_segments, int max_n, int32_t *d_order,
                              void *stream) {
+  SLAMHIP_BEGIN();
   if (n_total < 0 || dist_stride < 1 || n_segments < 1 || max_n < 0) return SLAMHIP_EINVAL;
   if (max_n > SLAMHIP_MAX_TRAIN_ROWS || n_segments > 65535) return SLAMHIP_EUNSUPPORTED;
   if (n_total == 0 || max_n == 0) return SLAMHIP_OK;

@@ -243,6 +243,7 @@ int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_m
                          const float *d_meas_r, int n, const double *d_Rt,
                          const uint8_t *d_valid, int h, const double *K, const double *M_right,
                          double thresh, int32_t *d_counts, void *stream) {
+  SLAMHIP_BEGIN();
   if (n < 0 || h < 0) return SLAMHIP_EINVAL;
   if (h == 0) return SLAMHIP_OK;
   if (!d_Rt || !d_counts || !K || !M_right) return SLAMHIP_EINVAL;
@@ -270,6 +271,7 @@ int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_m
 int slamhip_ransac_mask(const void *d_points, int points_fp64, const float *d_meas_l,
                         const float *d_meas_r, int n, const double *d_Rt_one, const double *K,
                         const double *M_right, double thresh, uint8_t *d_mask, void *stream) {
+  SLAMHIP_BEGIN();
   if (n < 0) return SLAMHIP_EINVAL;
   if (n == 0) return SLAMHIP_OK;
   if (!d_points || !d_meas_l || !d_meas_r || !d_Rt_one || !K || !M_right || !d_mask)
@@ -290,6 +292,7 @@ int slamhip_ransac_mask(const void *d_points, int points_fp64, const float *d_me
 
 int slamhip_ransac_replay(const int32_t *d_counts, int h, int n_points, double p_success,
                           int n_iter_max, int early_inliers, int32_t *d_result, void *stream) {
+  SLAMHIP_BEGIN();
   if (h < 0 || n_points < 1 || n_iter_max < 0) return SLAMHIP_EINVAL;
   if (!d_result || (h > 0 && !d_counts)) return SLAMHIP_EINVAL;
   hipLaunchKernelGGL(ransac_replay_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_counts, h,
@@ -300,6 +303,7 @@ int slamhip_ransac_replay(const int32_t *d_counts, int h, int n_points, double p
 
 int slamhip_project(const void *d_points, int points_fp64, int n, const double *P,
                     double *d_pixels, void *stream) {
+  SLAMHIP_BEGIN();
   if (n < 0) return SLAMHIP_EINVAL;
   if (n == 0) return SLAMHIP_OK;
   if (!d_points || !P || !d_pixels) return SLAMHIP_EINVAL;
@@ -319,6 +323,7 @@ int slamhip_project(const void *d_points, int points_fp64, int n, const double *
 int slamhip_supporters_pair(const double *d_meas_l, const double *d_proj_l,
                             const double *d_meas_r, const double *d_proj_r, int n, double thresh,
                             uint8_t *d_mask, void *stream) {
+  SLAMHIP_BEGIN();
   if (n < 0) return SLAMHIP_EINVAL;
   if (n == 0) return SLAMHIP_OK;
   if (!d_meas_l || !d_proj_l || !d_meas_r || !d_proj_r || !d_mask) return SLAMHIP_EINVAL;

@@ -61,14 +61,21 @@ def _desc_pair(q, t):
     return q, t
 
 
-def hamming_knn2(q, t) -> Tuple[torch.Tensor, torch.Tensor]:
+def hamming_knn2(q, t, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Top-2 Hamming neighbours of every row of q among the rows of t.
-    Returns (idx2, dist2): (nq, 2) int32 device tensors, -1 where absent."""
+    Returns (idx2, dist2): (nq, 2) int32 device tensors, -1 where absent.
+    `out` = preallocated (idx2, dist2) to write into."""
     q, t = _desc_pair(q, t)
     nq, nt = q.shape[0], t.shape[0]
     d = q.shape[1] if nq else (t.shape[1] if nt else 1)
-    idx2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
-    dist2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
+    if out is not None:
+        idx2, dist2 = out
+        if idx2.shape != (nq, 2) or dist2.shape != (nq, 2) or idx2.dtype != torch.int32 \
+                or dist2.dtype != torch.int32 or not idx2.is_contiguous() or not dist2.is_contiguous():
+            raise ValueError("out must be two contiguous (nq,2) int32 device tensors")
+    else:
+        idx2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
+        dist2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
     if nq == 0:
         return idx2, dist2
     if d < 1:
@@ -114,10 +121,12 @@ def hamming_knn2_batched(q, t, q_off, t_off, max_nq: Optional[int] = None,
     return idx2, dist2
 
 
-def ratio_test(dist2: torch.Tensor, ratio: float) -> torch.Tensor:
+def ratio_test(dist2: torch.Tensor, ratio: float, out=None) -> torch.Tensor:
     dist2 = to_device(dist2, torch.int32)
     nq = dist2.shape[0]
-    keep = torch.empty(nq, dtype=torch.uint8, device=dist2.device)
+    keep = out if out is not None else torch.empty(nq, dtype=torch.uint8, device=dist2.device)
+    if keep.numel() != nq or keep.dtype != torch.uint8:
+        raise ValueError("out must be a (nq,) uint8 device tensor")
     check(lib.slamhip_ratio_test(_ptr(dist2), nq, float(ratio), _ptr(keep), _stream()),
           "slamhip_ratio_test")
     return keep
