@@ -173,6 +173,33 @@ int slamhip_ransac_mask(const void *d_points, int points_fp64, const float *d_me
                         const double *K, const double *M_right, double thresh,
                         uint8_t *d_mask, void *stream);
 
+/* Minimal pose hypotheses: replaces PnP.solve_pnp(obj4, img4, cv2.SOLVEPNP_AP3P)
+ * (pnp.py:36-43) as called once per RANSAC iteration at pnp.py:126-128.
+ * Hypothesis i uses the four correspondences d_idx4[4i..4i+3] (rows of d_points
+ * (n,3) and d_pixels (n,2) float32); d_idx4 == NULL means rows 4i..4i+3.  The
+ * first three give up to four poses (P3P); the fourth selects the one with the
+ * smallest reprojection error in normalised image coordinates.  d_Rt (h,3,4)
+ * fp64, d_valid (h) uint8 (0 = no real solution with positive depths: the
+ * reference's `None`).  K is a HOST pointer (9 doubles). */
+int slamhip_p3p_solve(const void *d_points, int points_fp64, const float *d_pixels,
+                      const int32_t *d_idx4, int h, const double *K, double *d_Rt,
+                      uint8_t *d_valid, void *stream);
+
+/* Pose refinement: replaces PnP.solve_pnp(X[mask], pix_L[mask],
+ * cv2.SOLVEPNP_ITERATIVE) (fill_database.py:204-207, loop_closure.py:222):
+ * Levenberg-Marquardt on the left-image reprojection error from a given start.
+ * One workgroup per problem.  d_off != NULL: problem p owns rows
+ * [d_off[p], d_off[p+1]) of d_points (.,3) / d_pixels (.,2) float32 / d_mask
+ * (uint8, NULL = all rows); d_off == NULL: every problem uses the same n rows
+ * (several starts on one data set).  d_Rt_init / d_Rt_out: (n_problems,3,4)
+ * fp64; d_info (n_problems,2) fp64 = final sum of squared pixel errors and
+ * iterations used, may be NULL.  K: HOST pointer, 9 doubles, upper triangular
+ * with K[8] = 1. */
+int slamhip_refine_pose(const void *d_points, int points_fp64, const float *d_pixels,
+                        const uint8_t *d_mask, int n, const int32_t *d_off, int n_problems,
+                        const double *K, const double *d_Rt_init, int max_iters,
+                        double *d_Rt_out, double *d_info, void *stream);
+
 /* The two small helpers the reference exposes on its own:
  * PnP.project (pnp.py:94-99): pixels (n,2) fp64 = dehomogenised P @ [X,1];
  * P is a HOST pointer to 12 doubles.  PnP.supporters_pair (pnp.py:86-91) with

@@ -338,3 +338,111 @@ def sample_indices(n_points: int, n_iter: int, seed: int = 12345) -> np.ndarray:
     commented-out line pnp.py:120."""
     rng = np.random.default_rng(seed)
     return np.stack([rng.choice(n_points, 4, replace=False) for _ in range(n_iter)])
+
+
+# --------------------------------------------------------------------------
+# Minimal solver (stands where cv2.solvePnP(..., SOLVEPNP_AP3P) stands in
+# pnp.py:36-43).  PARITY UNPINNED: OpenCV is absent and the reference holds no
+# vectors for it.  Any exact P3P solver returns the same (up to four) poses for
+# three correspondences; this one forms the classical two-quadric system and
+# takes the quartic's roots from numpy.roots, independently of the bracketing
+# root finder of the HIP kernel.  The fourth correspondence selects the pose.
+# --------------------------------------------------------------------------
+
+
+def _triangle_frame(p1, p2, p3):
+    a = p2 - p1
+    a = a / np.linalg.norm(a)
+    n = np.cross(a, p3 - p1)
+    n = n / np.linalg.norm(n)
+    return np.column_stack([a, np.cross(n, a), n])
+
+
+def p3p_solutions(obj3, img3, K):
+    """All poses [R|t] (3x4) with positive depths for three correspondences."""
+    Kinv = np.linalg.inv(K)
+    b = (Kinv @ np.column_stack([img3, np.ones(3)]).T).T
+    f = b / np.linalg.norm(b, axis=1, keepdims=True)
+    X = np.asarray(obj3, dtype=np.float64)
+    a12 = np.sum((X[0] - X[1]) ** 2)
+    a13 = np.sum((X[0] - X[2]) ** 2)
+    a23 = np.sum((X[1] - X[2]) ** 2)
+    c12, c13, c23 = f[0] @ f[1], f[0] @ f[2], f[1] @ f[2]
+    P = np.polynomial.polynomial
+    A1, B1, C1 = a13, -2 * a13 * c12, np.array([a13 - a12, 2 * a12 * c13, -a12])
+    A2, B2, C2 = a23 - a12, np.array([-2 * a23 * c12, 2 * a12 * c23]), np.array([a23, 0.0, -a12])
+    p = A1 * C2 - A2 * C1
+    q = P.polysub(A1 * B2, [A2 * B1])
+    r = P.polysub(B1 * C2, P.polymul(B2, C1))
+    quart = P.polysub(P.polymul(p, p), P.polymul(q, r))
+    roots = np.roots(quart[::-1])
+    sols = []
+    Fw = _triangle_frame(X[0], X[1], X[2])
+    for v in roots:
+        if abs(v.imag) > 1e-9 * max(1.0, abs(v.real)) or v.real <= 0:
+            continue
+        v = v.real
+        qv = P.polyval(v, q)
+        if qv == 0:
+            continue
+        u = -P.polyval(v, p) / qv
+        if u <= 0:
+            continue
+        d1 = np.sqrt(a12 / (1 + u * u - 2 * u * c12))
+        d = np.array([d1, u * d1, v * d1])
+        for _ in range(3):  # Gauss-Newton polish of the depths
+            res = np.array([d[0] ** 2 + d[1] ** 2 - 2 * d[0] * d[1] * c12 - a12,
+                            d[0] ** 2 + d[2] ** 2 - 2 * d[0] * d[2] * c13 - a13,
+                            d[1] ** 2 + d[2] ** 2 - 2 * d[1] * d[2] * c23 - a23])
+            J = np.array([[2 * (d[0] - d[1] * c12), 2 * (d[1] - d[0] * c12), 0],
+                          [2 * (d[0] - d[2] * c13), 0, 2 * (d[2] - d[0] * c13)],
+                          [0, 2 * (d[1] - d[2] * c23), 2 * (d[2] - d[1] * c23)]])
+            d = d - np.linalg.solve(J, res)
+        if (d <= 0).any():
+            continue
+        Y = d[:, None] * f
+        R = _triangle_frame(Y[0], Y[1], Y[2]) @ Fw.T
+        t = Y[0] - R @ X[0]
+        sols.append(np.column_stack([R, t]))
+    return sols
+
+
+def p3p_solve(obj4, img4, K):
+    """Pose selected by the fourth correspondence, or None."""
+    obj4 = np.asarray(obj4, dtype=np.float64)
+    img4 = np.asarray(img4, dtype=np.float64)
+    sols = p3p_solutions(obj4[:3], img4[:3], K)
+    if not sols:
+        return None
+    n4 = np.linalg.inv(K) @ np.array([img4[3, 0], img4[3, 1], 1.0])
+    n4 = n4[:2] / n4[2]
+    best, best_err = None, np.inf
+    for Rt in sols:
+        c = Rt[:, :3] @ obj4[3] + Rt[:, 3]
+        err = np.sum((c[:2] / c[2] - n4) ** 2)
+        if err < best_err:
+            best, best_err = Rt, err
+    return best
+
+
+def refine_pose(obj, img, K, Rt0, mask=None):
+    """Least-squares pose (minimum of the left reprojection error) from a start,
+    standing where cv2.solvePnP(..., SOLVEPNP_ITERATIVE) stands
+    (fill_database.py:204-207).  PARITY UNPINNED (OpenCV absent); solved with
+    scipy.optimize.least_squares on a rotation-vector parametrisation."""
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+
+    obj = np.asarray(obj, dtype=np.float64)
+    img = np.asarray(img, dtype=np.float64)
+    if mask is not None:
+        obj, img = obj[mask], img[mask]
+    x0 = np.concatenate([Rotation.from_matrix(Rt0[:, :3]).as_rotvec(), Rt0[:, 3]])
+
+    def fun(x):
+        R = Rotation.from_rotvec(x[:3]).as_matrix()
+        return (project(obj, K @ np.column_stack([R, x[3:]])) - img).ravel()
+
+    sol = least_squares(fun, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    R = Rotation.from_rotvec(sol.x[:3]).as_matrix()
+    return np.column_stack([R, sol.x[3:]]), float(np.sum(sol.fun ** 2))

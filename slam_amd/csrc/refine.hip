@@ -1,0 +1,237 @@
+// Pose refinement on the inlier set: Levenberg-Marquardt on the left-image
+// reprojection error, one workgroup per problem, fp64.
+//
+// Role in the reference: PnP.solve_pnp(X[mask], pix_L[mask], cv2.SOLVEPNP_ITERATIVE)
+// after RANSAC (backend/tracking/fill_database.py:204-207,
+// backend/optimizers/loop_closure.py:222): the pose that minimises
+//   sum_i | proj(K (R X_i + t)) - m_i |^2   over the selected correspondences.
+// OpenCV reaches that minimum by LM from a DLT start; this kernel reaches the
+// same minimum by LM from the RANSAC winner (or any given start).
+//
+// Parametrisation: left-multiplied twist, Xc' = exp(w) Xc + v.  Each lane
+// accumulates the 21 + 6 normal-equation terms and the cost over its points;
+// wave shuffles + LDS fold them; lane 0 solves the damped 6x6 system (Cholesky)
+// and broadcasts the candidate pose through LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int kRefThreads = 256;
+
+struct Intr { double K[9]; };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+// exp of a rotation vector (Rodrigues), row-major 3x3
+__device__ void so3_exp(const double *w, double *R) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double th = sqrt(th2);
+  double a, b;  // sin(th)/th, (1-cos(th))/th^2
+  if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
+  else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  const double wx = w[0], wy = w[1], wz = w[2];
+  R[0] = 1.0 - b * (wy * wy + wz * wz); R[1] = -a * wz + b * wx * wy; R[2] = a * wy + b * wx * wz;
+  R[3] = a * wz + b * wx * wy; R[4] = 1.0 - b * (wx * wx + wz * wz); R[5] = -a * wx + b * wy * wz;
+  R[6] = -a * wy + b * wx * wz; R[7] = a * wx + b * wy * wz; R[8] = 1.0 - b * (wx * wx + wy * wy);
+}
+
+// Solve (H + lambda*diag(H)) x = -g for symmetric positive definite H (6x6,
+// upper triangle packed row-wise in h[21]).  Returns false if not SPD.
+__device__ bool solve_damped(const double *h, const double *g, double lambda, double *x) {
+  double A[6][6];
+  int k = 0;
+  for (int i = 0; i < 6; ++i)
+    for (int j = i; j < 6; ++j) { A[i][j] = h[k]; A[j][i] = h[k]; ++k; }
+  for (int i = 0; i < 6; ++i) A[i][i] += lambda * fmax(A[i][i], 1e-12);
+  double L[6][6];
+  for (int i = 0; i < 6; ++i)
+    for (int j = 0; j <= i; ++j) {
+      double s = A[i][j];
+      for (int m = 0; m < j; ++m) s -= L[i][m] * L[j][m];
+      if (i == j) {
+        if (!(s > 0.0)) return false;
+        L[i][i] = sqrt(s);
+      } else {
+        L[i][j] = s / L[j][j];
+      }
+    }
+  double y[6];
+  for (int i = 0; i < 6; ++i) {
+    double s = -g[i];
+    for (int m = 0; m < i; ++m) s -= L[i][m] * y[m];
+    y[i] = s / L[i][i];
+  }
+  for (int i = 5; i >= 0; --i) {
+    double s = y[i];
+    for (int m = i + 1; m < 6; ++m) s -= L[m][i] * x[m];
+    x[i] = s / L[i][i];
+  }
+  return true;
+}
+
+// One pass over the points at pose `Rt`: normal equations + cost, folded over
+// the workgroup into out[28] (valid in every lane of wave 0 after the call;
+// lane 0 of the block reads it from LDS).
+template <typename PT>
+__device__ void accumulate(const PT *__restrict__ pts, const float *__restrict__ pix,
+                           const uint8_t *__restrict__ mask, int n, const double *Rt,
+                           const Intr &in, double *lds /* [4][28] */, double *out /* [28] */) {
+  double acc[28];
+#pragma unroll
+  for (int i = 0; i < 28; ++i) acc[i] = 0.0;
+  const double fx = in.K[0], sk = in.K[1], cx = in.K[2], fy = in.K[4], cy = in.K[5];
+  for (int p = threadIdx.x; p < n; p += kRefThreads) {
+    if (mask != nullptr && mask[p] == 0) continue;
+    const double X = (double)pts[3 * (size_t)p], Y = (double)pts[3 * (size_t)p + 1],
+                 Z = (double)pts[3 * (size_t)p + 2];
+    const double xc = Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Rt[3];
+    const double yc = Rt[4] * X + Rt[5] * Y + Rt[6] * Z + Rt[7];
+    const double zc = Rt[8] * X + Rt[9] * Y + Rt[10] * Z + Rt[11];
+    const double iz = 1.0 / zc;
+    const double xn = xc * iz, yn = yc * iz;
+    const double ru = fx * xn + sk * yn + cx - (double)pix[2 * (size_t)p];
+    const double rv = fy * yn + cy - (double)pix[2 * (size_t)p + 1];
+    // d(u,v)/d(Xc): rows
+    const double ux = fx * iz, uy = sk * iz, uz = -(fx * xn + sk * yn) * iz;
+    const double vx = 0.0, vy = fy * iz, vz = -(fy * yn) * iz;
+    // columns: w (rotation) then v (translation); dXc/dw = -[Xc]x
+    double ju[6], jv[6];
+    ju[0] = uy * (-zc) + uz * yc;  // d/dwx: Xc' = w x Xc -> (0,-zc,yc)
+    ju[1] = ux * zc + uz * (-xc);  // d/dwy: (zc,0,-xc)
+    ju[2] = ux * (-yc) + uy * xc;  // d/dwz: (-yc,xc,0)
+    ju[3] = ux; ju[4] = uy; ju[5] = uz;
+    jv[0] = vy * (-zc) + vz * yc;
+    jv[1] = vx * zc + vz * (-xc);
+    jv[2] = vx * (-yc) + vy * xc;
+    jv[3] = vx; jv[4] = vy; jv[5] = vz;
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j) { acc[k] += ju[i] * ju[j] + jv[i] * jv[j]; ++k; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) acc[21 + i] += ju[i] * ru + jv[i] * rv;
+    acc[27] += ru * ru + rv * rv;
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < 28; ++i) {
+    const double s = wave_sum(acc[i]);
+    if (lane == 0) lds[wave * 28 + i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 28; ++i) out[i] = lds[i] + lds[28 + i] + lds[56 + i] + lds[84 + i];
+  __syncthreads();
+}
+
+template <typename PT>
+__global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
+    const PT *__restrict__ pts_all, const float *__restrict__ pix_all,
+    const uint8_t *__restrict__ mask_all, const int32_t *__restrict__ off, int n_single,
+    const double *__restrict__ Rt_init, Intr in, int max_iters, double *__restrict__ Rt_out,
+    double *__restrict__ info_out) {
+  __shared__ double lds[4 * 28];
+  __shared__ double sums[28];
+  __shared__ double pose[12];   // current accepted pose
+  __shared__ double cand[12];   // candidate pose
+  __shared__ int ctrl[2];       // [0] continue flag, [1] candidate exists
+  const int prob = blockIdx.x;
+  int p0 = 0, n = n_single;
+  if (off != nullptr) { p0 = off[prob]; n = off[prob + 1] - p0; }
+  const PT *pts = pts_all + 3 * (size_t)p0;
+  const float *pix = pix_all + 2 * (size_t)p0;
+  const uint8_t *mask = mask_all ? mask_all + p0 : nullptr;
+
+  if (threadIdx.x < 12) pose[threadIdx.x] = Rt_init[12 * (size_t)prob + threadIdx.x];
+  __syncthreads();
+  accumulate(pts, pix, mask, n, pose, in, lds, sums);
+
+  // lane 0 state
+  double H[21], g[6], cost = 0.0, lambda = 1e-6;
+  int iters = 0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < 21; ++i) H[i] = sums[i];
+    for (int i = 0; i < 6; ++i) g[i] = sums[21 + i];
+    cost = sums[27];
+  }
+  for (int it = 0; it < max_iters; ++it) {
+    if (threadIdx.x == 0) {
+      double dx[6];
+      bool ok = false;
+      for (int tries = 0; tries < 8 && !ok; ++tries) {
+        ok = solve_damped(H, g, lambda, dx);
+        if (!ok) lambda = fmax(lambda * 10.0, 1e-6);
+      }
+      double step = 0.0;
+      if (ok) for (int i = 0; i < 6; ++i) step = fmax(step, fabs(dx[i]));
+      if (!ok || step < 1e-13) {
+        ctrl[0] = 0;
+      } else {
+        double E[9];
+        so3_exp(dx, E);
+        for (int i = 0; i < 3; ++i) {
+          for (int j = 0; j < 4; ++j)
+            cand[4 * i + j] = E[3 * i] * pose[j] + E[3 * i + 1] * pose[4 + j] + E[3 * i + 2] * pose[8 + j];
+          cand[4 * i + 3] += dx[3 + i];
+        }
+        ctrl[0] = 1;
+      }
+    }
+    __syncthreads();
+    if (ctrl[0] == 0) break;
+    accumulate(pts, pix, mask, n, cand, in, lds, sums);
+    if (threadIdx.x == 0) {
+      ++iters;
+      const double new_cost = sums[27];
+      if (new_cost < cost) {
+        const double rel = (cost - new_cost) / fmax(cost, 1e-300);
+        for (int i = 0; i < 12; ++i) pose[i] = cand[i];
+        for (int i = 0; i < 21; ++i) H[i] = sums[i];
+        for (int i = 0; i < 6; ++i) g[i] = sums[21 + i];
+        cost = new_cost;
+        lambda = fmax(lambda * 0.1, 1e-12);
+        ctrl[1] = rel < 1e-15 ? 0 : 1;
+      } else {
+        lambda *= 10.0;
+        ctrl[1] = lambda > 1e12 ? 0 : 1;
+      }
+    }
+    __syncthreads();
+    if (ctrl[1] == 0) break;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) Rt_out[12 * (size_t)prob + threadIdx.x] = pose[threadIdx.x];
+  if (threadIdx.x == 0 && info_out != nullptr) {
+    info_out[2 * (size_t)prob] = cost;
+    info_out[2 * (size_t)prob + 1] = (double)iters;
+  }
+}
+
+}  // namespace
+
+extern "C" int slamhip_refine_pose(const void *d_points, int points_fp64, const float *d_pixels,
+                                   const uint8_t *d_mask, int n, const int32_t *d_off,
+                                   int n_problems, const double *K, const double *d_Rt_init,
+                                   int max_iters, double *d_Rt_out, double *d_info, void *stream) {
+  SLAMHIP_BEGIN();
+  if (n < 0 || n_problems < 1 || max_iters < 0) return SLAMHIP_EINVAL;
+  if (!d_points || !d_pixels || !K || !d_Rt_init || !d_Rt_out) return SLAMHIP_EINVAL;
+  Intr in;
+  for (int i = 0; i < 9; ++i) in.K[i] = K[i];
+  const dim3 grid(n_problems), block(kRefThreads);
+  if (points_fp64)
+    hipLaunchKernelGGL(refine_pose_kernel<double>, grid, block, 0, (hipStream_t)stream,
+                       (const double *)d_points, d_pixels, d_mask, d_off, d_off ? 0 : n, d_Rt_init,
+                       in, max_iters, d_Rt_out, d_info);
+  else
+    hipLaunchKernelGGL(refine_pose_kernel<float>, grid, block, 0, (hipStream_t)stream,
+                       (const float *)d_points, d_pixels, d_mask, d_off, d_off ? 0 : n, d_Rt_init,
+                       in, max_iters, d_Rt_out, d_info);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}

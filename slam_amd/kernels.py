@@ -270,3 +270,65 @@ def supporters_pair(meas_l, proj_l, meas_r, proj_r, thresh: float) -> torch.Tens
     check(lib.slamhip_supporters_pair(_ptr(ml), _ptr(pl), _ptr(mr), _ptr(pr), n, float(thresh),
                                       _ptr(mask), _stream()), "slamhip_supporters_pair")
     return mask
+
+
+def p3p_solve_indexed(points, pixels, idx4, K):
+    """Minimal pose per row of idx4 (h,4) into points (n,3) / pixels (n,2).
+    Returns (Rts (h,3,4) fp64, valid (h,) uint8) on the device."""
+    pts, fp64 = _points(points)
+    pix = to_device(pixels, torch.float32)
+    ix = None if idx4 is None else to_device(idx4, torch.int32)
+    h = ix.shape[0] if ix is not None else pts.shape[0] // 4
+    Rts = torch.empty((h, 3, 4), dtype=torch.float64, device=pts.device)
+    valid = torch.empty(h, dtype=torch.uint8, device=pts.device)
+    kp, _a = _lib.host_doubles(K, 9)
+    check(lib.slamhip_p3p_solve(_ptr(pts), 1 if fp64 else 0, _ptr(pix), _ptr(ix), h, kp, _ptr(Rts),
+                                _ptr(valid), _stream()), "slamhip_p3p_solve")
+    return Rts, valid
+
+
+def p3p_solve(obj4, img4, K):
+    """Minimal pose for each of h gathered samples: obj4 (h,4,3), img4 (h,4,2)."""
+    o = np.ascontiguousarray(obj4)
+    i = np.ascontiguousarray(img4, dtype=np.float32)
+    return p3p_solve_indexed(o.reshape(-1, 3), i.reshape(-1, 2), None, K)
+
+
+def refine_pose_from(points, pixels, mask, Rt_init, K, max_iters: int = 50):
+    """LM refinement of one or several starting poses on one data set.
+    Rt_init (3,4) or (s,3,4).  Returns (Rts (s,3,4), info (s,2) = cost, iters)."""
+    pts, fp64 = _points(points)
+    pix = to_device(pixels, torch.float32)
+    mk = None if mask is None else to_device(mask, torch.uint8)
+    init = to_device(Rt_init, torch.float64).reshape(-1, 3, 4)
+    s = init.shape[0]
+    out = torch.empty_like(init)
+    info = torch.empty((s, 2), dtype=torch.float64, device=pts.device)
+    kp, _a = _lib.host_doubles(K, 9)
+    check(lib.slamhip_refine_pose(_ptr(pts), 1 if fp64 else 0, _ptr(pix), _ptr(mk), pts.shape[0],
+                                  None, s, kp, _ptr(init), int(max_iters), _ptr(out), _ptr(info),
+                                  _stream()), "slamhip_refine_pose")
+    return out, info
+
+
+def refine_pose(obj, img, K, n_starts: int = 16):
+    """Least-squares pose over all correspondences with no start given: minimal
+    solutions of `n_starts` spread 4-samples seed the LM; the lowest final cost
+    wins.  Returns a (3,4) float64 NumPy array or None."""
+    obj = np.ascontiguousarray(obj)
+    img = np.ascontiguousarray(img, dtype=np.float32)
+    n = obj.shape[0]
+    if n < 4:
+        return None
+    base = np.arange(n_starts)[:, None] * max(1, n // n_starts)
+    idx4 = (base + np.array([0, n // 4, n // 2, (3 * n) // 4])[None, :]) % n
+    idx4 = idx4[[len(set(r)) == 4 for r in idx4.tolist()]]
+    if len(idx4) == 0:
+        return None
+    Rts, valid = p3p_solve_indexed(obj, img, idx4.astype(np.int32), K)
+    keep = valid.bool()
+    if not bool(keep.any().item()):
+        return None
+    out, info = refine_pose_from(obj, img, None, Rts[keep], K)
+    best = int(torch.argmin(info[:, 0]).item())
+    return out[best].cpu().numpy()

@@ -1,0 +1,130 @@
+"""GPU tests of the minimal solver (P3P + 4th point) and the LM pose refinement.
+OpenCV is absent, so both are checked against independent NumPy/SciPy solvers of
+the same problems and against ground truth (parity with cv2 itself: unpinned)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(rng, n, cam, sigma=0.0):
+    from scipy.spatial.transform import Rotation
+    X = np.column_stack([rng.uniform(-25, 25, n), rng.uniform(-3, 2, n), rng.uniform(4, 120, n)])
+    R = Rotation.from_rotvec(rng.normal(0, 0.03, 3)).as_matrix()
+    t = np.array([0.02, -0.01, -0.8]) + rng.normal(0, 0.05, 3)
+    Rt = np.column_stack([R, t])
+    pix = so.project(X, cam.K @ Rt) + rng.normal(0, sigma, (n, 2))
+    return X.astype(np.float32), pix.astype(np.float32), Rt
+
+
+def test_p3p_recovers_pose_and_matches_numpy_solver():
+    from slam_amd import kernels, CameraModel
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(1)
+    X, pix, Rt = _scene(rng, 600, cam)
+    idx4 = np.stack([rng.choice(600, 4, replace=False) for _ in range(500)]).astype(np.int32)
+    Rts, valid = kernels.p3p_solve_indexed(X, pix, idx4, cam.K)
+    Rts, valid = Rts.cpu().numpy(), valid.cpu().numpy()
+    assert valid.mean() > 0.98
+    n_ref_none = 0
+    for h in range(500):
+        ref = so.p3p_solve(X[idx4[h]], pix[idx4[h]], cam.K)
+        if ref is None:
+            n_ref_none += 1
+            continue
+        if not valid[h]:
+            continue
+        # the three sample points reproject onto their pixels
+        proj = so.project(X[idx4[h, :3]], cam.K @ Rts[h])
+        assert np.abs(proj - pix[idx4[h, :3]]).max() < 1e-7
+        assert np.abs(Rts[h] - ref).max() < 1e-6, (h, np.abs(Rts[h] - ref).max())
+        R = Rts[h][:, :3]
+        assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12 and np.linalg.det(R) > 0
+    # pixels are float32-rounded projections: pose error stays at that level
+    good = valid.astype(bool)
+    err = np.abs(Rts[good] - Rt).reshape(good.sum(), -1).max(axis=1)
+    assert np.median(err) < 1e-3
+    assert n_ref_none <= 10
+    # agreement on which samples have no solution at all is not required bit for bit,
+    # but a sample the NumPy solver solves must rarely be lost
+    lost = sum(1 for h in range(500) if not valid[h] and so.p3p_solve(X[idx4[h]], pix[idx4[h]], cam.K) is not None)
+    assert lost <= 5
+
+
+def test_p3p_degenerate_inputs_flagged_invalid():
+    from slam_amd import kernels, CameraModel
+    cam = CameraModel.kitti_like()
+    X = np.zeros((8, 3), np.float32)
+    X[:4] = [[1, 1, 10], [1, 1, 10], [2, 1, 12], [0, 0, 9]]          # repeated point
+    X[4:] = [[0, 0, 10], [1, 0, 10], [2, 0, 10], [3, 0, 10]]         # collinear
+    pix = so.project(X.astype(np.float64), cam.K @ np.hstack([np.eye(3), np.zeros((3, 1))])).astype(np.float32)
+    Rts, valid = kernels.p3p_solve(X.reshape(2, 4, 3), pix.reshape(2, 4, 2), cam.K)
+    assert valid.cpu().numpy().tolist() == [0, 0]
+    assert np.isfinite(Rts.cpu().numpy()).all()
+
+
+def test_refine_reaches_least_squares_minimum():
+    from slam_amd import kernels, CameraModel
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(4)
+    X, pix, Rt = _scene(rng, 400, cam, sigma=0.5)
+    mask = (rng.random(400) < 0.8).astype(np.uint8)
+    start = Rt.copy()
+    start[:, 3] += [0.05, -0.03, 0.1]
+    out, info = kernels.refine_pose_from(X, pix, mask, start, cam.K)
+    out, info = out.cpu().numpy()[0], info.cpu().numpy()[0]
+    ref, ref_cost = so.refine_pose(X, pix, cam.K, start, mask.astype(bool))
+    assert abs(info[0] - ref_cost) <= 1e-9 * ref_cost
+    assert np.abs(out - ref).max() < 1e-7, np.abs(out - ref).max()
+    R = out[:, :3]
+    assert np.abs(R @ R.T - np.eye(3)).max() < 1e-12
+    # several starts on one data set end in the same minimum
+    starts = np.stack([start, Rt, ref])
+    outs, infos = kernels.refine_pose_from(X, pix, mask, starts, cam.K)
+    assert np.abs(outs.cpu().numpy() - out).max() < 1e-7
+    # no usable point at all: the start is returned unchanged
+    o2, _ = kernels.refine_pose_from(X, pix, np.zeros(400, np.uint8), start, cam.K)
+    np.testing.assert_array_equal(o2.cpu().numpy()[0], start)
+
+
+def test_pnp_facade_solve_pnp_and_full_ransac():
+    from slam_amd import PnP, CameraModel, SOLVEPNP_AP3P, SOLVEPNP_ITERATIVE
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(6)
+    n = 550
+    X, mL, Rt = _scene(rng, n, cam, sigma=0.5)
+    Rt_R = (so.homogenous(cam.M_right) @ so.homogenous(Rt))[:3]
+    mR = (so.project(X, cam.K @ Rt_R) + rng.normal(0, 0.5, (n, 2))).astype(np.float32)
+    bad = rng.random(n) < 0.35
+    mL[bad] += rng.normal(0, 30, (int(bad.sum()), 2)).astype(np.float32)
+    pnp = PnP(cam, pixel_thresh=4.0)
+    Rt4 = pnp.solve_pnp(X[:4][~bad[:4]] if False else X[np.flatnonzero(~bad)[:4]],
+                        mL[np.flatnonzero(~bad)[:4]], SOLVEPNP_AP3P)
+    assert Rt4 is not None and Rt4.shape == (3, 4)
+    assert pnp.solve_pnp(X[:3], mL[:3], SOLVEPNP_AP3P) is None
+    # full adaptive RANSAC with the device minimal solver, seeded sampling
+    mask = pnp.ransac_pnp_pair1(X, mL, mR, rng=np.random.default_rng(12345))
+    assert mask is not None and mask.dtype == bool and mask.shape == (n,)
+    assert mask[~bad].mean() > 0.9 and mask[bad].mean() < 0.05
+    # replaying the same sample sequence through the CPU checker gives the same mask
+    rng2 = np.random.default_rng(12345)
+    counts, Rts = [], []
+    for _ in range(256):
+        idx4 = rng2.choice(n, 4, replace=False)
+        est = so.p3p_solve(X[idx4], mL[idx4], cam.K)
+        Rts.append(est)
+        counts.append(-1 if est is None else int(so.hypothesis_mask(cam.K, cam.M_right, est, X, mL, mR, 4.0).sum()))
+    best, best_count, it, req = so.ransac_replay(counts, n)
+    assert it < 256
+    ref_mask = so.hypothesis_mask(cam.K, cam.M_right, Rts[best], X, mL, mR, 4.0)
+    assert (mask != ref_mask).sum() <= 2      # minimal-solver rounding can move a borderline point
+    # refinement on the inliers (the call at fill_database.py:204-207)
+    Rt_ref = pnp.solve_pnp(X[mask], mL[mask], SOLVEPNP_ITERATIVE)
+    gold, _ = so.refine_pose(X[mask], mL[mask], cam.K, Rt)
+    assert np.abs(Rt_ref - gold).max() < 1e-6
+    assert np.abs(Rt_ref - Rt).max() < 5e-3
+    with pytest.raises(ValueError):
+        pnp.solve_pnp(X, mL, 99)
