@@ -222,6 +222,60 @@ int slamhip_ransac_replay(const int32_t *d_counts, int h, int n_points, double p
                           int n_iter_max, int early_inliers, int32_t *d_result,
                           void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* Batched front-end: the per-frame data flow of TrackingPipeline.build()    */
+/* (backend/tracking/fill_database.py:140-240) for n_frames consecutive      */
+/* frames in a fixed number of launches, features given.                     */
+/*                                                                           */
+/* Stereo stage per frame f (fill_database.py:155-169): match L->R (k=1),    */
+/* sort by distance (stable), row/disparity filter, triangulate survivors,   */
+/* gather their left descriptors (TrackingDB.create_links order,             */
+/* backend/tracking/database.py:279-283).                                    */
+/* Temporal stage per pair (f, f+1) (fill_database.py:185-207): match inlier */
+/* descriptors of f (query) against those of f+1 (train), sort, build        */
+/* X_corr / pix_L / pix_R, adaptive RANSAC over P3P hypotheses with stereo   */
+/* consensus (pnp.py:102-160), LM refinement on the inliers.                 */
+/*                                                                           */
+/* All per-frame output arrays are indexed from the frame's LEFT offset      */
+/* d_off_left[f]; counts are in d_st_count / d_ransac_info.                  */
+/* ------------------------------------------------------------------------- */
+typedef struct slamhip_frontend_args {
+  /* inputs (device unless noted) */
+  int32_t n_frames;                      /* F >= 1 */
+  int32_t n_left_total, n_right_total;   /* rows of the concatenated arrays */
+  int32_t max_left, max_right;           /* largest per-frame feature counts (host bound) */
+  int32_t desc_bytes, desc_stride;
+  const float *d_kp_left, *d_kp_right;       /* (.,2) float32 pixels */
+  const uint8_t *d_des_left, *d_des_right;   /* (.,desc_stride) uint8 */
+  const int32_t *d_off_left, *d_off_right;   /* F+1 row offsets */
+  /* camera and parameters (host values) */
+  double K[9], M_right[12], P_left[12], P_right[12];
+  double pixel_thresh, disparity_min;    /* stereo filter (triangulation.py:104) */
+  double ransac_thresh, p_success;       /* pnp.py:91, :104 */
+  int32_t n_iter_max, refine_iters;
+  uint64_t seed;                         /* device sampler seed */
+  const int32_t *d_samples;  /* optional (F-1, n_iter_max, 4) sample indices into each pair's
+                                sorted temporal matches; NULL = device RNG */
+  /* outputs */
+  int32_t *d_st_count;                   /* F: stereo inliers per frame */
+  int32_t *d_st_left, *d_st_right, *d_st_dist; /* n_left_total: inlier (left kp, right kp, dist) */
+  float *d_st_xyz;                       /* n_left_total*3: triangulated points */
+  float *d_st_pix_left, *d_st_pix_right; /* n_left_total*2: inlier pixels */
+  uint32_t *d_st_desc;                   /* n_left_total*W dwords: inlier left descriptors, zero
+                                            padded to W = 8/16/32 dwords */
+  int32_t *d_tm_query, *d_tm_train, *d_tm_dist; /* n_left_total: sorted temporal matches of pair f
+                                            at d_off_left[f] (indices into the inlier sets) */
+  uint8_t *d_tm_mask;                    /* n_left_total: RANSAC inlier mask, same order */
+  double *d_pose_ransac, *d_pose_refined;/* (F-1)*12: winning hypothesis, refined [R|t] */
+  int32_t *d_ransac_info;                /* (F-1)*8: best index, best count, iterations, final
+                                            n_iter_required, math-domain flag, N, mask count, 0 */
+  void *d_workspace;
+  size_t workspace_bytes;
+} slamhip_frontend_args;
+
+size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *args);
+int slamhip_frontend_batch(const slamhip_frontend_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,83 @@
+"""
+CPU restatement of the per-frame data flow of TrackingPipeline.build()
+(backend/tracking/fill_database.py:102-240 of the reference), features given.
+TEST INFRASTRUCTURE ONLY (see oracle/slam_oracle.py for the pinning status of
+each step; the steps that live in OpenCV are parity unpinned).
+
+It is deliberately written the way the reference is: one frame at a time, one
+RANSAC iteration at a time, so that it also serves as the shape of the CPU
+baseline ("a Python loop over frames calling array kernels").
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import slam_oracle as so
+
+
+def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2):
+    """fill_database.py:155-169 for one frame."""
+    kp_l, kp_r, des_l, des_r = frame
+    qi, ti, di = so.bf_match(des_l, des_r)                                  # :155
+    keep = so.stereo_filter(kp_l, kp_r, qi, ti, pixel_thresh, disparity_min)  # :158-160
+    qi, ti, di = qi[keep], ti[keep], di[keep]
+    X = so.triangulate_cv(cam.P_left, cam.P_right, kp_l[qi], kp_r[ti])      # :163
+    return {"left_idx": qi, "right_idx": ti, "dist": di, "xyz": X,
+            "inlier_des_left": des_l[qi],                                   # create_links, :166-169
+            "pix_left": kp_l[qi], "pix_right": kp_r[ti]}
+
+
+def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
+                   p_success=0.99999, n_iter_max=2500, rng=None):
+    """fill_database.py:185-207 for one pair.  `samples` (n_iter,4) fixes the
+    idx4 sequence (else rng.choice as in pnp.py:126); `solver(obj4,img4)` is the
+    minimal solver (default: oracle P3P)."""
+    qi, ti, di = so.bf_match(prev["inlier_des_left"], curr["inlier_des_left"])   # :185
+    if len(curr["inlier_des_left"]) == 0:
+        qi, ti, di = qi[:0], ti[:0], di[:0]
+    X_corr = prev["xyz"][qi]                                                      # :189-190
+    pix_L, pix_R = curr["pix_left"][ti], curr["pix_right"][ti]                    # :195-197
+    N = len(X_corr)
+    out = {"query_idx": qi, "train_idx": ti, "dist": di, "n_matches": N, "X_corr": X_corr,
+           "pix_L": pix_L, "pix_R": pix_R, "mask": np.zeros(N, bool), "best_index": -1,
+           "best_count": 0, "iterations": 0, "Rt_ransac": None, "hyps": []}
+    if N < 4:
+        return out
+    if solver is None:
+        solver = lambda o, i: so.p3p_solve(o, i, cam.K)
+    if rng is None:
+        rng = np.random.default_rng()
+    # pnp.py:110-160, one iteration at a time
+    best_mask, best_count, best_idx, best_Rt = None, 0, -1, None
+    iter_done, n_req = 0, n_iter_max
+    import math
+    while iter_done < n_req and iter_done < n_iter_max:
+        idx4 = samples[iter_done] if samples is not None else rng.choice(N, 4, replace=False)
+        it = iter_done
+        iter_done += 1
+        Rt = solver(X_corr[idx4], pix_L[idx4])
+        out["hyps"].append(Rt)
+        if Rt is None:
+            continue
+        mask = so.hypothesis_mask(cam.K, cam.M_right, Rt, X_corr, pix_L, pix_R, pixel_thresh)
+        inl = int(mask.sum())
+        if inl > best_count:
+            best_count, best_mask, best_idx, best_Rt = inl, mask, it, Rt
+            w = best_count / N
+            if w > 0:
+                n_req = math.ceil(math.log(1 - p_success) / math.log(1 - w ** 4))
+    out.update(mask=best_mask if best_mask is not None else out["mask"], best_index=best_idx,
+               best_count=best_count, iterations=iter_done, Rt_ransac=best_Rt, n_iter_required=n_req)
+    return out
+
+
+def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=True, **kw):
+    stereo = [stereo_stage(cam, f, pixel_thresh, disparity_min) for f in frames]
+    pairs = []
+    for p in range(len(frames) - 1):
+        s = None if samples is None else samples[p]
+        t = temporal_stage(cam, stereo[p], stereo[p + 1], pixel_thresh, samples=s, **kw)
+        if refine and t["Rt_ransac"] is not None and t["mask"].sum() >= 3:
+            t["Rt"], _ = so.refine_pose(t["X_corr"], t["pix_L"], cam.K, t["Rt_ransac"], t["mask"])
+        pairs.append(t)
+    return stereo, pairs

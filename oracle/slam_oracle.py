@@ -428,8 +428,12 @@ def p3p_solve(obj4, img4, K):
 def refine_pose(obj, img, K, Rt0, mask=None):
     """Least-squares pose (minimum of the left reprojection error) from a start,
     standing where cv2.solvePnP(..., SOLVEPNP_ITERATIVE) stands
-    (fill_database.py:204-207).  PARITY UNPINNED (OpenCV absent); solved with
-    scipy.optimize.least_squares on a rotation-vector parametrisation."""
+    (fill_database.py:204-207).  PARITY UNPINNED (OpenCV absent).
+
+    SciPy's MINPACK LM brings the start into the basin (its finite-difference
+    Jacobian limits it to ~1e-7 in weak directions); Gauss-Newton steps with the
+    analytic Jacobian (numpy.linalg.lstsq on the stacked 2n x 6 system) then
+    converge to the stationary point.  Returns ([R|t], sum of squared errors)."""
     from scipy.optimize import least_squares
     from scipy.spatial.transform import Rotation
 
@@ -445,4 +449,29 @@ def refine_pose(obj, img, K, Rt0, mask=None):
 
     sol = least_squares(fun, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
     R = Rotation.from_rotvec(sol.x[:3]).as_matrix()
-    return np.column_stack([R, sol.x[3:]]), float(np.sum(sol.fun ** 2))
+    t = sol.x[3:].copy()
+    for _ in range(20):
+        Xc = obj @ R.T + t
+        p = Xc @ K.T
+        res = (p[:, :2] / p[:, 2:3] - img).ravel()
+        # d(pixel)/d(Xc) = (d(p/pz)/dp) K ;  d(Xc)/d(w, v) = [-[Xc]x | I]
+        n = len(obj)
+        dpix_dp = np.zeros((n, 2, 3))
+        dpix_dp[:, 0, 0] = 1 / p[:, 2]
+        dpix_dp[:, 1, 1] = 1 / p[:, 2]
+        dpix_dp[:, 0, 2] = -p[:, 0] / p[:, 2] ** 2
+        dpix_dp[:, 1, 2] = -p[:, 1] / p[:, 2] ** 2
+        dpix_dX = dpix_dp @ K
+        skew = np.zeros((n, 3, 3))
+        skew[:, 0, 1], skew[:, 0, 2] = -Xc[:, 2], Xc[:, 1]
+        skew[:, 1, 0], skew[:, 1, 2] = Xc[:, 2], -Xc[:, 0]
+        skew[:, 2, 0], skew[:, 2, 1] = -Xc[:, 1], Xc[:, 0]
+        J = np.concatenate([dpix_dX @ (-skew), dpix_dX], axis=2).reshape(2 * n, 6)
+        delta = np.linalg.lstsq(J, -res, rcond=None)[0]
+        E = Rotation.from_rotvec(delta[:3]).as_matrix()
+        R, t = E @ R, E @ t + delta[3:]
+        if np.abs(delta).max() < 1e-14:
+            break
+    Rt = np.column_stack([R, t])
+    final = (project(obj, K @ Rt) - img).ravel()
+    return Rt, float(np.sum(final ** 2))

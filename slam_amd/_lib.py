@@ -65,6 +65,31 @@ SIGNATURES = {
     "slamhip_ransac_replay": (_i, [_vp, _i, _i, _d, _i, _i, _vp, _vp]),
 }
 
+_i32, _u64 = C.c_int32, C.c_uint64
+
+
+class FrontendArgs(C.Structure):
+    """Mirror of `slamhip_frontend_args` (include/slamhip.h), field for field."""
+    _fields_ = [
+        ("n_frames", _i32), ("n_left_total", _i32), ("n_right_total", _i32),
+        ("max_left", _i32), ("max_right", _i32), ("desc_bytes", _i32), ("desc_stride", _i32),
+        ("d_kp_left", _vp), ("d_kp_right", _vp), ("d_des_left", _vp), ("d_des_right", _vp),
+        ("d_off_left", _vp), ("d_off_right", _vp),
+        ("K", C.c_double * 9), ("M_right", C.c_double * 12),
+        ("P_left", C.c_double * 12), ("P_right", C.c_double * 12),
+        ("pixel_thresh", _d), ("disparity_min", _d), ("ransac_thresh", _d), ("p_success", _d),
+        ("n_iter_max", _i32), ("refine_iters", _i32), ("seed", _u64), ("d_samples", _vp),
+        ("d_st_count", _vp), ("d_st_left", _vp), ("d_st_right", _vp), ("d_st_dist", _vp),
+        ("d_st_xyz", _vp), ("d_st_pix_left", _vp), ("d_st_pix_right", _vp), ("d_st_desc", _vp),
+        ("d_tm_query", _vp), ("d_tm_train", _vp), ("d_tm_dist", _vp), ("d_tm_mask", _vp),
+        ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_ransac_info", _vp),
+        ("d_workspace", _vp), ("workspace_bytes", _sz),
+    ]
+
+
+SIGNATURES["slamhip_frontend_workspace_bytes"] = (_sz, [C.POINTER(FrontendArgs)])
+SIGNATURES["slamhip_frontend_batch"] = (_i, [C.POINTER(FrontendArgs), _vp])
+
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library disagree
     _fn.restype = _res

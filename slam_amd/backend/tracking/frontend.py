@@ -1,0 +1,187 @@
+"""Batched front-end: the per-frame data flow of the reference's
+TrackingPipeline.build() (backend/tracking/fill_database.py:85-255) with
+features given, executed by `slamhip_frontend_batch` for a whole run of frames
+at once.
+
+A frame is (kp_left (n,2) float32, kp_right (m,2) float32, des_left (n,D) uint8,
+des_right (m,D) uint8).  `run` returns device tensors; `FrontendResult.frame(f)`
+/ `.pair(p)` give NumPy views shaped like what the reference builds per frame:
+stereo inlier matches in sorted order, triangulated points, links, the inlier
+descriptor subset, temporal matches (sorted), the RANSAC inlier mask and the
+relative pose [R|t] (the rows of `relative_Rts`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ..._lib import lib, check, FrontendArgs
+from ... import kernels
+
+Frame = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]
+
+
+@dataclass
+class FrontendInputs:
+    """Concatenated, device-resident inputs of a run of frames."""
+    n_frames: int
+    off_left: np.ndarray      # (F+1,) int32 host copy
+    off_right: np.ndarray
+    d_off_left: torch.Tensor
+    d_off_right: torch.Tensor
+    kp_left: torch.Tensor
+    kp_right: torch.Tensor
+    des_left: torch.Tensor
+    des_right: torch.Tensor
+
+    @property
+    def desc_bytes(self) -> int:
+        return int(self.des_left.shape[1])
+
+
+class FrontendResult:
+    def __init__(self, inputs: FrontendInputs, W: int, t: dict):
+        self.inputs, self.W, self.t = inputs, W, t
+        self._host = None
+
+    def to_host(self) -> dict:
+        if self._host is None:
+            torch.cuda.synchronize()
+            self._host = {k: v.cpu().numpy() for k, v in self.t.items()}
+        return self._host
+
+    # ------------------------------------------------------------ per-frame views
+    def frame(self, f: int) -> dict:
+        h = self.to_host()
+        b = int(self.inputs.off_left[f])
+        m = int(h["st_count"][f])
+        sl = slice(b, b + m)
+        desc = h["st_desc"].reshape(-1, self.W)[sl].view(np.uint8)[:, :self.inputs.desc_bytes]
+        pl, pr = h["st_pix_left"].reshape(-1, 2)[sl], h["st_pix_right"].reshape(-1, 2)[sl]
+        return {
+            "left_idx": h["st_left"][sl], "right_idx": h["st_right"][sl], "dist": h["st_dist"][sl],
+            "xyz": h["st_xyz"].reshape(-1, 3)[sl], "pix_left": pl, "pix_right": pr,
+            "inlier_des_left": desc,
+            # Link(x_left, x_right, y) of TrackingDB.create_links (database.py:276)
+            "links": np.column_stack([pl[:, 0].astype(np.float64), pr[:, 0].astype(np.float64),
+                                      (pl[:, 1].astype(np.float64) + pr[:, 1].astype(np.float64)) / 2]),
+        }
+
+    def pair(self, p: int) -> dict:
+        """Temporal stage of frames (p, p+1)."""
+        h = self.to_host()
+        b = int(self.inputs.off_left[p])
+        info = h["ransac_info"].reshape(-1, 8)[p]
+        n = int(info[5])
+        sl = slice(b, b + n)
+        return {
+            "query_idx": h["tm_query"][sl], "train_idx": h["tm_train"][sl], "dist": h["tm_dist"][sl],
+            "mask": h["tm_mask"][sl].astype(bool),
+            "Rt_ransac": h["pose_ransac"].reshape(-1, 3, 4)[p],
+            "Rt": h["pose_refined"].reshape(-1, 3, 4)[p],
+            "best_index": int(info[0]), "best_count": int(info[1]), "iterations": int(info[2]),
+            "n_iter_required": int(info[3]), "domain_error": bool(info[4]), "n_matches": n,
+        }
+
+    def relative_Rts(self) -> np.ndarray:
+        """(F-1,3,4): what the reference pickles as `relative_Rts`
+        (fill_database.py:252-255)."""
+        return self.to_host()["pose_refined"].reshape(-1, 3, 4).copy()
+
+
+class TrackingFrontend:
+    """Parameters follow the reference's defaults: disparity_min / pixel_thresh
+    (run_slam.py:31-32; pixel_thresh is shared by the stereo filter and the PnP
+    inlier test, fill_database.py:81-82), p_success and n_iter_max (pnp.py:104-105)."""
+
+    def __init__(self, cam, disparity_min: float = 1.2, pixel_thresh: float = 4.0,
+                 p_success: float = 0.99999, n_iter_max: int = 2500, refine_iters: int = 30,
+                 seed: int = 0):
+        self.cam = cam
+        self.disparity_min, self.pixel_thresh = float(disparity_min), float(pixel_thresh)
+        self.p_success, self.n_iter_max = float(p_success), int(n_iter_max)
+        self.refine_iters, self.seed = int(refine_iters), int(seed)
+        self._ws = None
+
+    # ------------------------------------------------------------------ staging
+    @staticmethod
+    def upload(frames: Sequence[Frame]) -> FrontendInputs:
+        if len(frames) < 1:
+            raise ValueError("need at least one frame")
+        nl = [len(f[0]) for f in frames]
+        nr = [len(f[1]) for f in frames]
+        for f in frames:
+            if len(f[2]) != len(f[0]) or len(f[3]) != len(f[1]):
+                raise ValueError("keypoints and descriptors differ in length")
+        off_l = np.concatenate([[0], np.cumsum(nl)]).astype(np.int32)
+        off_r = np.concatenate([[0], np.cumsum(nr)]).astype(np.int32)
+        d = frames[0][2].shape[1]
+        cat = lambda i, dt, w: (np.concatenate([np.asarray(f[i], dtype=dt).reshape(-1, w) for f in frames])
+                                if len(frames) else np.zeros((0, w), dt))
+        dev = kernels.to_device
+        return FrontendInputs(len(frames), off_l, off_r, dev(off_l, torch.int32), dev(off_r, torch.int32),
+                              dev(cat(0, np.float32, 2), torch.float32), dev(cat(1, np.float32, 2), torch.float32),
+                              dev(cat(2, np.uint8, d), torch.uint8), dev(cat(3, np.uint8, d), torch.uint8))
+
+    # ---------------------------------------------------------------------- run
+    def run(self, frames_or_inputs, samples: Optional[np.ndarray] = None) -> FrontendResult:
+        inp = frames_or_inputs if isinstance(frames_or_inputs, FrontendInputs) else self.upload(frames_or_inputs)
+        F = inp.n_frames
+        NL, NR = int(inp.off_left[-1]), int(inp.off_right[-1])
+        D = inp.desc_bytes
+        W = 8 if D <= 32 else (16 if D <= 64 else 32)
+        dev = inp.kp_left.device
+        i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+        f32 = lambda n: torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        t = {
+            "st_count": i32(F), "st_left": i32(NL), "st_right": i32(NL), "st_dist": i32(NL),
+            "st_xyz": f32(NL * 3), "st_pix_left": f32(NL * 2), "st_pix_right": f32(NL * 2),
+            "st_desc": torch.zeros(max(NL * W, 1), dtype=torch.int32, device=dev),
+            "tm_query": i32(NL), "tm_train": i32(NL), "tm_dist": i32(NL),
+            "tm_mask": torch.zeros(max(NL, 1), dtype=torch.uint8, device=dev),
+            "pose_ransac": torch.zeros(max(F - 1, 1) * 12, dtype=torch.float64, device=dev),
+            "pose_refined": torch.zeros(max(F - 1, 1) * 12, dtype=torch.float64, device=dev),
+            "ransac_info": torch.zeros(max(F - 1, 1) * 8, dtype=torch.int32, device=dev),
+        }
+        a = FrontendArgs()
+        a.n_frames, a.n_left_total, a.n_right_total = F, NL, NR
+        a.max_left = int(np.diff(inp.off_left).max()) if F else 0
+        a.max_right = int(np.diff(inp.off_right).max()) if F else 0
+        a.desc_bytes = a.desc_stride = D
+        a.d_kp_left, a.d_kp_right = inp.kp_left.data_ptr(), inp.kp_right.data_ptr()
+        a.d_des_left, a.d_des_right = inp.des_left.data_ptr(), inp.des_right.data_ptr()
+        a.d_off_left, a.d_off_right = inp.d_off_left.data_ptr(), inp.d_off_right.data_ptr()
+        for name, src, n in (("K", self.cam.K, 9), ("M_right", self.cam.M_right, 12),
+                             ("P_left", self.cam.P_left, 12), ("P_right", self.cam.P_right, 12)):
+            vals = np.asarray(src, dtype=np.float64).reshape(-1)
+            if vals.size != n:
+                raise ValueError(f"camera.{name} has the wrong shape")
+            setattr(a, name, (C.c_double * n)(*vals.tolist()))
+        a.pixel_thresh, a.disparity_min = self.pixel_thresh, self.disparity_min
+        a.ransac_thresh, a.p_success = self.pixel_thresh, self.p_success
+        a.n_iter_max, a.refine_iters, a.seed = self.n_iter_max, self.refine_iters, self.seed
+        d_samples = None
+        if samples is not None:
+            samples = np.ascontiguousarray(samples, dtype=np.int32)
+            if samples.shape != (max(F - 1, 0), self.n_iter_max, 4):
+                raise ValueError("samples must have shape (n_frames-1, n_iter_max, 4)")
+            d_samples = kernels.to_device(samples, torch.int32)
+            a.d_samples = d_samples.data_ptr()
+        for k, v in t.items():
+            setattr(a, "d_" + k, v.data_ptr())
+        need = lib.slamhip_frontend_workspace_bytes(C.byref(a))
+        if need == 0:
+            check(_lib.EUNSUPPORTED, "slamhip_frontend_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.d_workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        check(lib.slamhip_frontend_batch(C.byref(a), torch.cuda.current_stream().cuda_stream),
+              "slamhip_frontend_batch")
+        res = FrontendResult(inp, W, t)
+        res._keepalive = (d_samples,)
+        return res

@@ -25,3 +25,26 @@ static inline int slamhip_packed_words(int desc_bytes) {
   if (desc_bytes <= 64) return 16;
   return 32;
 }
+
+// Cross-translation-unit entry points (not part of the C ABI).
+namespace slamhip_internal {
+size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
+                            int desc_bytes);
+// Batched top-2 matcher.  prepacked: rows are already W-dword packed (row_stride
+// = 4*W, 16-byte aligned).  Pair p owns query rows [q_off[p], q_off[p] + count)
+// with count = q_cnt[p] (or q_off[p+1]-q_off[p] when q_cnt is NULL); same for t.
+int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total, int desc_bytes,
+         int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
+         const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
+         int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
+         hipStream_t st);
+int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
+              uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
+int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,
+                     const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order,
+                     hipStream_t st);
+int refine_pose(const void *d_points, int points_fp64, const float *d_pixels, const uint8_t *d_mask,
+                const int32_t *d_off, const int32_t *d_cnt, int n_problems, const double *K,
+                const double *d_Rt_init, int max_iters, double *d_Rt_out, double *d_info,
+                hipStream_t st);
+}  // namespace slamhip_internal

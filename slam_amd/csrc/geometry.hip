@@ -14,84 +14,11 @@
 // value keeps full relative accuracy.
 #include "common.h"
 
+#include "dlt_device.h"
+
 namespace {
 
-struct CamPair {
-  double PL[12];
-  double PR[12];
-};
-
-constexpr int kMaxSweeps = 12;
-
-// Rotate columns p and q of the 4x4 A (a[row][col]) and of V so that the two
-// columns of A become orthogonal.  Returns true when a rotation was applied.
-template <int P, int Qc>
-__device__ __forceinline__ bool jacobi_pair(double (&a)[4][4], double (&v)[4][4]) {
-  double alpha = 0.0, beta = 0.0, gamma = 0.0;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    alpha = fma(a[i][P], a[i][P], alpha);
-    beta = fma(a[i][Qc], a[i][Qc], beta);
-    gamma = fma(a[i][P], a[i][Qc], gamma);
-  }
-  // Columns already orthogonal to working precision.
-  if (fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta) || gamma == 0.0) return false;
-  const double zeta = (beta - alpha) / (2.0 * gamma);
-  const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-  const double c = 1.0 / sqrt(fma(t, t, 1.0));
-  const double s = c * t;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const double ap = a[i][P], aq = a[i][Qc];
-    a[i][P] = c * ap - s * aq;
-    a[i][Qc] = s * ap + c * aq;
-    const double vp = v[i][P], vq = v[i][Qc];
-    v[i][P] = c * vp - s * vq;
-    v[i][Qc] = s * vp + c * vq;
-  }
-  return true;
-}
-
-// Unit right singular vector of the smallest singular value of A.
-__device__ __forceinline__ void smallest_right_singular_vector(double (&a)[4][4], double (&x)[4]) {
-  double v[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[i][j] = (i == j) ? 1.0 : 0.0;
-
-  for (int sweep = 0; sweep < kMaxSweeps; ++sweep) {
-    bool any = false;
-    any |= jacobi_pair<0, 1>(a, v);
-    any |= jacobi_pair<0, 2>(a, v);
-    any |= jacobi_pair<0, 3>(a, v);
-    any |= jacobi_pair<1, 2>(a, v);
-    any |= jacobi_pair<1, 3>(a, v);
-    any |= jacobi_pair<2, 3>(a, v);
-    if (!any) break;
-  }
-  double n[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    n[j] = 0.0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) n[j] = fma(a[i][j], a[i][j], n[j]);
-  }
-  // Column with the smallest norm (lowest index on exact ties).
-  int k = 0;
-  double best = n[0];
-#pragma unroll
-  for (int j = 1; j < 4; ++j)
-    if (n[j] < best) { best = n[j]; k = j; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-    x[i] = k == 0 ? v[i][0] : (k == 1 ? v[i][1] : (k == 2 ? v[i][2] : v[i][3]));
-  // V is a product of rotations, so the column is unit length up to rounding;
-  // renormalise so the fp32 rounding below sees a unit vector like an SVD's.
-  const double inv = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] *= inv;
-}
+using namespace slamhip_dev;
 
 template <typename KP>
 __global__ __launch_bounds__(256) void filter_triangulate_kernel(
@@ -110,23 +37,15 @@ __global__ __launch_bounds__(256) void filter_triangulate_kernel(
 
   bool ok = true;
   if (keep != nullptr) {
-    ok = (fabs(vR - vL) <= pix_thresh) && ((uL - uR) >= disp_min);
+    ok = stereo_keep(uL, vL, uR, vR, pix_thresh, disp_min);
     keep[k] = ok ? 1 : 0;
   }
 
   double X = 0.0, Y = 0.0, Z = 0.0;
   float Xf = 0.f, Yf = 0.f, Zf = 0.f;
   if (ok) {
-    double a[4][4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      a[0][c] = uL * cam.PL[8 + c] - cam.PL[0 + c];
-      a[1][c] = vL * cam.PL[8 + c] - cam.PL[4 + c];
-      a[2][c] = uR * cam.PR[8 + c] - cam.PR[0 + c];
-      a[3][c] = vR * cam.PR[8 + c] - cam.PR[4 + c];
-    }
     double x[4];
-    smallest_right_singular_vector(a, x);
+    dlt_null_vector(cam, uL, vL, uR, vR, x);
     if (out_fp64) {
       X = x[0] / x[3];
       Y = x[1] / x[3];

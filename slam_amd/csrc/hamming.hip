@@ -76,16 +76,17 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
 template <int W, int Q, bool USE_LDS>
 __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
-    const int32_t *__restrict__ q_off, const int32_t *__restrict__ t_off, int nq_single,
+    const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
+    const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt, int nq_single,
     int nt_single, int nq_total, uint2 *__restrict__ partial, int32_t *__restrict__ idx2,
     int32_t *__restrict__ dist2) {
   const int pair = blockIdx.z;
   int q0 = 0, nq = nq_single, t0 = 0, nt = nt_single;
   if (q_off != nullptr) {
     q0 = q_off[pair];
-    nq = q_off[pair + 1] - q0;
+    nq = q_cnt ? q_cnt[pair] : q_off[pair + 1] - q0;
     t0 = t_off[pair];
-    nt = t_off[pair + 1] - t0;
+    nt = t_cnt ? t_cnt[pair] : t_off[pair + 1] - t0;
   }
   const int qblk = blockIdx.x * (kThreads * Q);
   if (qblk >= nq) return;  // block-uniform
@@ -257,13 +258,14 @@ __global__ __launch_bounds__(256) void cross_check_kernel(const int32_t *__restr
 __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t *__restrict__ dist,
                                                         int dist_stride, int n_single,
                                                         const int32_t *__restrict__ off,
+                                                        const int32_t *__restrict__ cnt,
                                                         int32_t *__restrict__ order) {
   __shared__ __align__(16) uint32_t keys[1024];
   const int seg = blockIdx.y;
   int s0 = 0, n = n_single;
   if (off != nullptr) {
     s0 = off[seg];
-    n = off[seg + 1] - s0;
+    n = cnt ? cnt[seg] : off[seg + 1] - s0;
   }
   const int i0 = blockIdx.x * 256;
   if (i0 >= n) return;
@@ -353,16 +355,18 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
 
 template <int W, int Q, bool L>
 void launch_top2(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp,
-                 const int32_t *q_off, const int32_t *t_off, int nq, int nt, int nq_total,
-                 uint2 *part, int32_t *idx2, int32_t *dist2) {
+                 const int32_t *q_off, const int32_t *q_cnt, const int32_t *t_off,
+                 const int32_t *t_cnt, int nq, int nt, int nq_total, uint2 *part, int32_t *idx2,
+                 int32_t *dist2) {
   hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L>), grid, dim3(kThreads), 0, st, qp, tp, q_off,
-                     t_off, nq, nt, nq_total, part, idx2, dist2);
+                     q_cnt, t_off, t_cnt, nq, nt, nq_total, part, idx2, dist2);
 }
 
 int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total,
              int desc_bytes, int row_stride, const int32_t *d_q_off, const int32_t *d_t_off,
              int n_pairs, int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
-             void *d_workspace, size_t workspace_bytes, void *stream) {
+             void *d_workspace, size_t workspace_bytes, void *stream, bool prepacked = false,
+             const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr) {
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
     return SLAMHIP_EINVAL;
   if (desc_bytes < 1 || row_stride < desc_bytes) return SLAMHIP_EINVAL;
@@ -384,7 +388,13 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   uint32_t *tp = (uint32_t *)(base + p.off_tp);
   uint2 *part = (uint2 *)(base + p.off_part);
 
-  {
+  if (prepacked) {
+    // rows are already W dwords each, 16-byte aligned
+    if (row_stride != p.W * 4 || ((uintptr_t)d_query & 15) || ((uintptr_t)d_train & 15))
+      return SLAMHIP_EINVAL;
+    qp = (uint32_t *)d_query;
+    tp = (uint32_t *)d_train;
+  } else {
     const long long total = ((long long)nq_total + nt_total) * p.W;
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, d_query, nq_total, qp,
@@ -400,8 +410,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   }
   const int nqs = d_q_off ? 0 : nq_total, nts = d_q_off ? 0 : nt_total;
 #define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
-  launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_t_off, nqs, nts, nq_total, part, d_idx2, \
-                          d_dist2)
+  launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, nqs, nts, nq_total, \
+                          part, d_idx2, d_dist2)
   if (p.W == 8) {
     if (p.Q == 2) { if (p.use_lds) SLAMHIP_DISPATCH(8, 2, true); else SLAMHIP_DISPATCH(8, 2, false); }
     else          { if (p.use_lds) SLAMHIP_DISPATCH(8, 1, true); else SLAMHIP_DISPATCH(8, 1, false); }
@@ -534,9 +544,51 @@ int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total
   if (n_segments > 1 && !d_off) return SLAMHIP_EINVAL;
   const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
   hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_dist,
-                     dist_stride, d_off ? 0 : n_total, d_off, d_order);
+                     dist_stride, d_off ? 0 : n_total, d_off, (const int32_t *)nullptr, d_order);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }
 
 }  // extern "C"
+
+// Entry points for the other translation units of the library.
+namespace slamhip_internal {
+
+size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
+                            int desc_bytes) {
+  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes).total;
+}
+
+int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total, int desc_bytes,
+         int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
+         const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
+         int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
+         hipStream_t st) {
+  return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
+                  n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, (void *)st,
+                  prepacked, d_q_cnt, d_t_cnt);
+}
+
+int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
+              uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st) {
+  const int W = slamhip_packed_words(desc_bytes);
+  const long long total = ((long long)n_a + n_b) * W;
+  if (total == 0) return SLAMHIP_OK;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_a,
+                     n_a, d_dst_a, d_b, n_b, d_dst_b, desc_bytes, row_stride, W);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,
+                     const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order,
+                     hipStream_t st) {
+  if (max_n <= 0 || n_segments <= 0) return SLAMHIP_OK;
+  const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
+  hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, st, d_dist, dist_stride, 0, d_off, d_cnt,
+                     d_order);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+}  // namespace slamhip_internal

@@ -19,116 +19,11 @@
 //   alignment of the two triangles.
 #include "common.h"
 
+#include "p3p_device.h"
+
 namespace {
 
-struct Kinv { double m[9]; };
-
-__device__ __forceinline__ double horner(const double *c, int deg, double x) {
-  double r = c[deg];
-  for (int i = deg - 1; i >= 0; --i) r = fma(r, x, c[i]);
-  return r;
-}
-
-// Root of polynomial c (degree deg) inside [lo, hi] given a sign change; bisection
-// with Newton acceleration, always kept inside the bracket.
-__device__ double bracketed_root(const double *c, int deg, double lo, double hi, double flo) {
-  double d[4];
-  for (int i = 1; i <= deg; ++i) d[i - 1] = c[i] * (double)i;
-  double x = 0.5 * (lo + hi);
-  for (int it = 0; it < 64; ++it) {
-    const double fx = horner(c, deg, x);
-    if (fx == 0.0) return x;
-    if ((fx < 0.0) == (flo < 0.0)) lo = x; else hi = x;
-    const double dfx = horner(d, deg - 1, x);
-    double xn = x - fx / dfx;
-    if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-    if (fabs(xn - x) <= 4.4e-16 * fmax(1.0, fabs(xn))) return xn;
-    x = xn;
-  }
-  return x;
-}
-
-// Real roots of c[0] + c[1] x + ... + c[deg] x^deg (deg <= 4, c[deg] != 0) inside
-// [-bound, bound], ascending.  `crit` = sorted real roots of the derivative.
-__device__ int roots_between(const double *c, int deg, const double *crit, int ncrit, double bound,
-                             double *out) {
-  int n = 0;
-  double lo = -bound, flo = horner(c, deg, lo);
-  for (int k = 0; k <= ncrit; ++k) {
-    const double hi = (k < ncrit) ? fmin(fmax(crit[k], -bound), bound) : bound;
-    const double fhi = horner(c, deg, hi);
-    if (flo == 0.0) {
-      if (n == 0 || out[n - 1] != lo) out[n++] = lo;
-    } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0)) && hi > lo) {
-      out[n++] = bracketed_root(c, deg, lo, hi, flo);
-    }
-    lo = hi;
-    flo = fhi;
-    if (n >= deg) break;
-  }
-  if (n < deg && flo == 0.0 && (n == 0 || out[n - 1] != lo)) out[n++] = lo;
-  return n;
-}
-
-__device__ double cauchy_bound(const double *c, int deg) {
-  double m = 0.0;
-  for (int i = 0; i < deg; ++i) m = fmax(m, fabs(c[i] / c[deg]));
-  return 1.0 + m;
-}
-
-__device__ int quartic_real_roots(const double *q, double *roots) {
-  // q has degree 4 with q[4] != 0
-  double c3[4], c2[3];
-  for (int i = 1; i <= 4; ++i) c3[i - 1] = q[i] * (double)i;
-  for (int i = 1; i <= 3; ++i) c2[i - 1] = c3[i] * (double)i;
-  // quadratic c2 roots
-  double r2[2];
-  int n2 = 0;
-  {
-    const double a = c2[2], b = c2[1], c = c2[0];
-    const double disc = b * b - 4.0 * a * c;
-    if (disc >= 0.0) {
-      const double s = sqrt(disc);
-      const double qq = -0.5 * (b + copysign(s, b));
-      double x1 = qq / a, x2 = (qq != 0.0) ? c / qq : x1;
-      if (x1 > x2) { const double t = x1; x1 = x2; x2 = t; }
-      r2[0] = x1; r2[1] = x2; n2 = (x1 == x2) ? 1 : 2;
-    }
-  }
-  double r3[3];
-  const int n3 = roots_between(c3, 3, r2, n2, cauchy_bound(c3, 3), r3);
-  return roots_between(q, 4, r3, n3, cauchy_bound(q, 4), roots);
-}
-
-__device__ __forceinline__ void cross3(const double *a, const double *b, double *o) {
-  o[0] = a[1] * b[2] - a[2] * b[1];
-  o[1] = a[2] * b[0] - a[0] * b[2];
-  o[2] = a[0] * b[1] - a[1] * b[0];
-}
-__device__ __forceinline__ double dot3(const double *a, const double *b) {
-  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
-}
-__device__ __forceinline__ bool normalize3(double *a) {
-  const double n = sqrt(dot3(a, a));
-  if (!(n > 0.0)) return false;
-  const double inv = 1.0 / n;
-  a[0] *= inv; a[1] *= inv; a[2] *= inv;
-  return true;
-}
-
-// Orthonormal frame (columns e1,e2,e3) of the triangle p1,p2,p3.
-__device__ bool triangle_frame(const double *p1, const double *p2, const double *p3, double (&F)[3][3]) {
-  double a[3] = {p2[0] - p1[0], p2[1] - p1[1], p2[2] - p1[2]};
-  double b[3] = {p3[0] - p1[0], p3[1] - p1[1], p3[2] - p1[2]};
-  if (!normalize3(a)) return false;
-  double n[3];
-  cross3(a, b, n);
-  if (!normalize3(n)) return false;
-  double m[3];
-  cross3(n, a, m);
-  for (int i = 0; i < 3; ++i) { F[i][0] = a[i]; F[i][1] = m[i]; F[i][2] = n[i]; }
-  return true;
-}
+using namespace slamhip_dev;
 
 template <typename PT>
 __global__ __launch_bounds__(64) void p3p_kernel(const PT *__restrict__ pts,
@@ -138,116 +33,19 @@ __global__ __launch_bounds__(64) void p3p_kernel(const PT *__restrict__ pts,
                                                  uint8_t *__restrict__ valid_out) {
   const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
   if (hyp >= h) return;
-  double X[4][3], f[4][3], nrm[4][2];
+  double X[4][3], f[4][3], nrm4[2];
   for (int k = 0; k < 4; ++k) {
     const size_t r = idx4 ? (size_t)idx4[4 * (size_t)hyp + k] : (size_t)(4 * (size_t)hyp + k);
     for (int c = 0; c < 3; ++c) X[k][c] = (double)pts[3 * r + c];
-    const double u = (double)pix[2 * r + 0], v = (double)pix[2 * r + 1];
-    double b[3];
-    for (int c = 0; c < 3; ++c) b[c] = ki.m[3 * c + 0] * u + ki.m[3 * c + 1] * v + ki.m[3 * c + 2];
-    nrm[k][0] = b[0] / b[2];
-    nrm[k][1] = b[1] / b[2];
-    normalize3(b);
-    for (int c = 0; c < 3; ++c) f[k][c] = b[c];
+    double nk[2];
+    pixel_to_bearing(ki, (double)pix[2 * r + 0], (double)pix[2 * r + 1], f[k], nk);
+    if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
   }
-  double *out = Rt_out + 12 * (size_t)hyp;
-  bool found = false;
-  double best_err = 1.79e308, bestRt[12];
-
-  double d12[3], d13[3], d23[3];
-  for (int c = 0; c < 3; ++c) {
-    d12[c] = X[0][c] - X[1][c];
-    d13[c] = X[0][c] - X[2][c];
-    d23[c] = X[1][c] - X[2][c];
-  }
-  const double a12 = dot3(d12, d12), a13 = dot3(d13, d13), a23 = dot3(d23, d23);
-  const double c12 = dot3(f[0], f[1]), c13 = dot3(f[0], f[2]), c23 = dot3(f[1], f[2]);
-  double Fw[3][3];
-  const bool world_ok = a12 > 0.0 && a13 > 0.0 && a23 > 0.0 && triangle_frame(X[0], X[1], X[2], Fw);
-
-  if (world_ok) {
-    // E1: A1 u^2 + B1 u + C1(v) = 0,  E2: A2 u^2 + B2(v) u + C2(v) = 0
-    const double A1 = a13, B1 = -2.0 * a13 * c12;
-    const double C1[3] = {a13 - a12, 2.0 * a12 * c13, -a12};
-    const double A2 = a23 - a12;
-    const double B2[2] = {-2.0 * a23 * c12, 2.0 * a12 * c23};
-    const double C2[3] = {a23, 0.0, -a12};
-    double p[3], q[2], r[4];
-    for (int i = 0; i < 3; ++i) p[i] = A1 * C2[i] - A2 * C1[i];           // A1 C2 - A2 C1
-    q[0] = A1 * B2[0] - A2 * B1;                                            // A1 B2 - A2 B1
-    q[1] = A1 * B2[1];
-    r[0] = B1 * C2[0] - B2[0] * C1[0];                                      // B1 C2 - B2 C1
-    r[1] = B1 * C2[1] - (B2[0] * C1[1] + B2[1] * C1[0]);
-    r[2] = B1 * C2[2] - (B2[0] * C1[2] + B2[1] * C1[1]);
-    r[3] = -(B2[1] * C1[2]);
-    double quart[5] = {0, 0, 0, 0, 0};                                      // p^2 - q r
-    for (int i = 0; i < 3; ++i)
-      for (int j = 0; j < 3; ++j) quart[i + j] += p[i] * p[j];
-    for (int i = 0; i < 2; ++i)
-      for (int j = 0; j < 4; ++j) quart[i + j] -= q[i] * r[j];
-    double scale = 0.0;
-    for (int i = 0; i < 5; ++i) scale = fmax(scale, fabs(quart[i]));
-    double vr[4];
-    int nroots = 0;
-    if (scale > 0.0 && fabs(quart[4]) > 1e-14 * scale) nroots = quartic_real_roots(quart, vr);
-
-    for (int s = 0; s < nroots; ++s) {
-      const double v = vr[s];
-      if (!(v > 0.0)) continue;
-      const double qv = q[0] + q[1] * v;
-      if (qv == 0.0) continue;
-      const double u = -(p[0] + v * (p[1] + v * p[2])) / qv;
-      if (!(u > 0.0)) continue;
-      const double den = 1.0 + u * u - 2.0 * u * c12;
-      if (!(den > 0.0)) continue;
-      double d[3];
-      d[0] = sqrt(a12 / den);
-      d[1] = u * d[0];
-      d[2] = v * d[0];
-      // two Gauss-Newton steps on the three distance equations
-      for (int it = 0; it < 2; ++it) {
-        const double r0 = d[0] * d[0] + d[1] * d[1] - 2.0 * d[0] * d[1] * c12 - a12;
-        const double r1 = d[0] * d[0] + d[2] * d[2] - 2.0 * d[0] * d[2] * c13 - a13;
-        const double r2 = d[1] * d[1] + d[2] * d[2] - 2.0 * d[1] * d[2] * c23 - a23;
-        const double j00 = 2.0 * (d[0] - d[1] * c12), j01 = 2.0 * (d[1] - d[0] * c12);
-        const double j10 = 2.0 * (d[0] - d[2] * c13), j12 = 2.0 * (d[2] - d[0] * c13);
-        const double j21 = 2.0 * (d[1] - d[2] * c23), j22 = 2.0 * (d[2] - d[1] * c23);
-        // J = [[j00 j01 0],[j10 0 j12],[0 j21 j22]]
-        const double det = -j00 * j12 * j21 - j01 * j10 * j22;
-        if (fabs(det) < 1e-300) break;
-        const double inv = 1.0 / det;
-        const double dx0 = inv * (r0 * (-j12 * j21) - j01 * (r1 * j22 - j12 * r2));
-        const double dx1 = inv * (j00 * (r1 * j22 - j12 * r2) - r0 * (j10 * j22));
-        const double dx2 = inv * (j00 * (-j21 * r1) - j01 * (j10 * r2) + r0 * (j10 * j21));
-        d[0] -= dx0; d[1] -= dx1; d[2] -= dx2;
-      }
-      if (!(d[0] > 0.0 && d[1] > 0.0 && d[2] > 0.0)) continue;
-      double Y[3][3];
-      for (int k = 0; k < 3; ++k)
-        for (int c = 0; c < 3; ++c) Y[k][c] = d[k] * f[k][c];
-      double Fc[3][3];
-      if (!triangle_frame(Y[0], Y[1], Y[2], Fc)) continue;
-      double Rt[12];
-      for (int i = 0; i < 3; ++i)
-        for (int j = 0; j < 3; ++j)
-          Rt[4 * i + j] = Fc[i][0] * Fw[j][0] + Fc[i][1] * Fw[j][1] + Fc[i][2] * Fw[j][2];
-      for (int i = 0; i < 3; ++i)
-        Rt[4 * i + 3] = Y[0][i] - (Rt[4 * i] * X[0][0] + Rt[4 * i + 1] * X[0][1] + Rt[4 * i + 2] * X[0][2]);
-      // fourth point, error in normalised image coordinates
-      double c4[3];
-      for (int i = 0; i < 3; ++i)
-        c4[i] = Rt[4 * i] * X[3][0] + Rt[4 * i + 1] * X[3][1] + Rt[4 * i + 2] * X[3][2] + Rt[4 * i + 3];
-      const double ex = c4[0] / c4[2] - nrm[3][0], ey = c4[1] / c4[2] - nrm[3][1];
-      const double err = ex * ex + ey * ey;
-      if (err < best_err) {
-        best_err = err;
-        found = true;
-        for (int i = 0; i < 12; ++i) bestRt[i] = Rt[i];
-      }
-    }
-  }
+  double Rt[12];
+  const bool found = p3p_lane(X, f, nrm4, Rt);
   valid_out[hyp] = found ? 1 : 0;
-  for (int i = 0; i < 12; ++i) out[i] = found ? bestRt[i] : 0.0;
+  double *out = Rt_out + 12 * (size_t)hyp;
+  for (int i = 0; i < 12; ++i) out[i] = found ? Rt[i] : 0.0;
 }
 
 bool invert3(const double *K, double *o) {

@@ -132,8 +132,8 @@ __device__ void accumulate(const PT *__restrict__ pts, const float *__restrict__
 template <typename PT>
 __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
     const PT *__restrict__ pts_all, const float *__restrict__ pix_all,
-    const uint8_t *__restrict__ mask_all, const int32_t *__restrict__ off, int n_single,
-    const double *__restrict__ Rt_init, Intr in, int max_iters, double *__restrict__ Rt_out,
+    const uint8_t *__restrict__ mask_all, const int32_t *__restrict__ off,
+    const int32_t *__restrict__ cnt, int n_single, const double *__restrict__ Rt_init, Intr in, int max_iters, double *__restrict__ Rt_out,
     double *__restrict__ info_out) {
   __shared__ double lds[4 * 28];
   __shared__ double sums[28];
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
   __shared__ int ctrl[2];       // [0] continue flag, [1] candidate exists
   const int prob = blockIdx.x;
   int p0 = 0, n = n_single;
-  if (off != nullptr) { p0 = off[prob]; n = off[prob + 1] - p0; }
+  if (off != nullptr) { p0 = off[prob]; n = cnt ? cnt[prob] : off[prob + 1] - p0; }
   const PT *pts = pts_all + 3 * (size_t)p0;
   const float *pix = pix_all + 2 * (size_t)p0;
   const uint8_t *mask = mask_all ? mask_all + p0 : nullptr;
@@ -226,12 +226,30 @@ extern "C" int slamhip_refine_pose(const void *d_points, int points_fp64, const 
   const dim3 grid(n_problems), block(kRefThreads);
   if (points_fp64)
     hipLaunchKernelGGL(refine_pose_kernel<double>, grid, block, 0, (hipStream_t)stream,
-                       (const double *)d_points, d_pixels, d_mask, d_off, d_off ? 0 : n, d_Rt_init,
-                       in, max_iters, d_Rt_out, d_info);
+                       (const double *)d_points, d_pixels, d_mask, d_off, (const int32_t *)nullptr,
+                       d_off ? 0 : n, d_Rt_init, in, max_iters, d_Rt_out, d_info);
   else
     hipLaunchKernelGGL(refine_pose_kernel<float>, grid, block, 0, (hipStream_t)stream,
-                       (const float *)d_points, d_pixels, d_mask, d_off, d_off ? 0 : n, d_Rt_init,
-                       in, max_iters, d_Rt_out, d_info);
+                       (const float *)d_points, d_pixels, d_mask, d_off, (const int32_t *)nullptr,
+                       d_off ? 0 : n, d_Rt_init, in, max_iters, d_Rt_out, d_info);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_internal::refine_pose(const void *d_points, int points_fp64, const float *d_pixels,
+                                  const uint8_t *d_mask, const int32_t *d_off, const int32_t *d_cnt,
+                                  int n_problems, const double *K, const double *d_Rt_init,
+                                  int max_iters, double *d_Rt_out, double *d_info, hipStream_t st) {
+  if (n_problems <= 0) return SLAMHIP_OK;
+  Intr in;
+  for (int i = 0; i < 9; ++i) in.K[i] = K[i];
+  const dim3 grid(n_problems), block(kRefThreads);
+  if (points_fp64)
+    hipLaunchKernelGGL(refine_pose_kernel<double>, grid, block, 0, st, (const double *)d_points,
+                       d_pixels, d_mask, d_off, d_cnt, 0, d_Rt_init, in, max_iters, d_Rt_out, d_info);
+  else
+    hipLaunchKernelGGL(refine_pose_kernel<float>, grid, block, 0, st, (const float *)d_points,
+                       d_pixels, d_mask, d_off, d_cnt, 0, d_Rt_init, in, max_iters, d_Rt_out, d_info);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }
