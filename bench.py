@@ -79,12 +79,114 @@ def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 1.5):
     }, idx2, dist2
 
 
+def bench_frontend(args, rank, world, dist):
+    """Secondary measurement (BASELINE configs[2]/[3] shape): the whole per-frame
+    front-end (stereo match, filter, triangulate, temporal match, adaptive P3P
+    RANSAC, LM refinement) over `--frames` synthetic KITTI-shaped frames per GPU,
+    features resident in HBM.  With N > 1 every rank processes its own frame
+    range and the per-frame records are gathered once (all_gather over RCCL)."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking import sharding
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+
+    cam = CameraModel.kitti_like()
+    F = args.frames
+    seq = StereoSequence(cam, n_frames=F, n_features=1500, seed=100 + rank, clutter=0.6)
+    frames = []
+    for k in range(F):
+        f = seq.frame(k)
+        frames.append((f.kp_left, f.kp_right, f.des_left, f.des_right))
+    fe = TrackingFrontend(cam, seed=rank)
+    inputs = fe.upload(frames)
+
+    def step():
+        res = fe.run(inputs)
+        if dist is not None:
+            own_f = [res.frame(i) for i in range(F)]
+            own_p = [res.pair(i) for i in range(F - 1)]
+            blob = sharding.pack_records(own_f, own_p, rank * F, rank * (F - 1), 61)
+            sharding.all_gather_records(blob)
+        return res
+
+    for _ in range(2):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.frontend_steps):
+        res = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return None
+    h = res.to_host()
+    info = h["ransac_info"].reshape(-1, 8)
+    out = {
+        "metric": "frontend_frames_per_sec",
+        "value": F * args.frontend_steps * world / elapsed,
+        "unit": "frames/s",
+        "ms_per_frame": elapsed / (F * args.frontend_steps) * 1e3,
+        "workload": f"{F} synthetic KITTI-shaped stereo frames per GPU (1226x370, 1500 AKAZE-like "
+                    f"features per image, 61-byte descriptors), full front-end per frame, features given"
+                    + ("" if world == 1 else "; per-frame records gathered once per pass (all_gather)"),
+        "steps": args.frontend_steps,
+        "stereo_inliers_mean": float(h["st_count"][:F].mean()),
+        "temporal_matches_mean": float(info[:, 5].mean()),
+        "ransac_inlier_ratio_mean": float((info[:, 1] / np.maximum(info[:, 5], 1)).mean()),
+        "ransac_iterations_mean": float(info[:, 2].mean()),
+        "pose_error_vs_truth_max_m": float(max(
+            np.abs(res.pair(p)["Rt"][:, 3] - seq.relative_pose(p + 1)[:, 3]).max() for p in range(0, F - 1, 25))),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_frontend(cam, frames[:7])
+        out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+    return out
+
+
+def cpu_baseline_frontend(cam, frames):
+    """Frame-at-a-time CPU restatement (oracle/pipeline_oracle.py: NumPy geometry,
+    C/OpenMP matcher, one RANSAC iteration at a time like pnp.py:123-158)."""
+    from oracle import pipeline_oracle as po
+    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    lib = C.CDLL(path)
+    lib.oracle_hamming_knn2.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_void_p, C.c_void_p, C.c_int]
+    lib.oracle_hamming_knn2.restype = None
+    lib.oracle_max_threads.restype = C.c_int
+
+    def knn2(q, t):
+        q = np.ascontiguousarray(q); t = np.ascontiguousarray(t)
+        i2 = np.empty((len(q), 2), np.int32); d2 = np.empty((len(q), 2), np.int32)
+        lib.oracle_hamming_knn2(q.ctypes.data, len(q), t.ctypes.data, len(t), q.shape[1], q.shape[1],
+                                i2.ctypes.data, d2.ctypes.data, 0)
+        return i2, d2
+    t0 = time.perf_counter()
+    po.run(cam, frames, rng=np.random.default_rng(0), knn2=knn2)
+    dt = time.perf_counter() - t0
+    return {"value": (len(frames) - 1) / dt, "unit": "frames/s", "cores": int(lib.oracle_max_threads()),
+            "kind": "port",
+            "sample": f"{len(frames) - 1} frame pairs, frame-at-a-time NumPy/SciPy restatement of "
+                      f"fill_database.py:140-240 with the C/OpenMP matcher and a NumPy P3P "
+                      f"(cv2 absent: its C++ AP3P would be faster per iteration), {dt:.2f} s wall"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--frames", type=int, default=500,
+                    help="frames per GPU of the secondary front-end measurement (0 = skip)")
+    ap.add_argument("--frontend-steps", type=int, default=5)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -150,6 +252,10 @@ def main():
     n_launch = _lib.lib.slamhip_profile_end(C.byref(total_ms))
     kernel_s = (total_ms.value / max(n_launch, 1)) * 1e-3
 
+    frontend = None
+    if args.frames >= 2:
+        frontend = bench_frontend(args, rank, world, dist)
+
     if rank == 0:
         compares = float(NQ) * NT
         achieved = compares * OPS_PER_COMPARE / kernel_s
@@ -178,6 +284,8 @@ def main():
                          "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
                          "traffic": None},
         }
+        if frontend is not None:
+            line["frontend"] = frontend
         if world == 1 and not args.no_cpu_baseline:
             res = cpu_baseline(q_np, t_np)
             if res is not None:

@@ -15,10 +15,22 @@ import numpy as np
 from . import slam_oracle as so
 
 
-def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2):
+def _bf_match(q, t, knn2=None):
+    """bf_match with an optional faster top-2 routine (the C oracle)."""
+    if knn2 is None:
+        return so.bf_match(q, t)
+    if len(q) == 0 or len(t) == 0:
+        z = np.zeros(0, np.int32)
+        return z, z, z
+    idx2, dist2 = knn2(q, t)
+    order = np.argsort(dist2[:, 0], kind="stable")
+    return order.astype(np.int32), idx2[order, 0], dist2[order, 0]
+
+
+def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2, knn2=None):
     """fill_database.py:155-169 for one frame."""
     kp_l, kp_r, des_l, des_r = frame
-    qi, ti, di = so.bf_match(des_l, des_r)                                  # :155
+    qi, ti, di = _bf_match(des_l, des_r, knn2)                              # :155
     keep = so.stereo_filter(kp_l, kp_r, qi, ti, pixel_thresh, disparity_min)  # :158-160
     qi, ti, di = qi[keep], ti[keep], di[keep]
     X = so.triangulate_cv(cam.P_left, cam.P_right, kp_l[qi], kp_r[ti])      # :163
@@ -28,11 +40,11 @@ def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2):
 
 
 def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
-                   p_success=0.99999, n_iter_max=2500, rng=None):
+                   p_success=0.99999, n_iter_max=2500, rng=None, knn2=None):
     """fill_database.py:185-207 for one pair.  `samples` (n_iter,4) fixes the
     idx4 sequence (else rng.choice as in pnp.py:126); `solver(obj4,img4)` is the
     minimal solver (default: oracle P3P)."""
-    qi, ti, di = so.bf_match(prev["inlier_des_left"], curr["inlier_des_left"])   # :185
+    qi, ti, di = _bf_match(prev["inlier_des_left"], curr["inlier_des_left"], knn2)  # :185
     if len(curr["inlier_des_left"]) == 0:
         qi, ti, di = qi[:0], ti[:0], di[:0]
     X_corr = prev["xyz"][qi]                                                      # :189-190
@@ -72,7 +84,7 @@ def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
 
 
 def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=True, **kw):
-    stereo = [stereo_stage(cam, f, pixel_thresh, disparity_min) for f in frames]
+    stereo = [stereo_stage(cam, f, pixel_thresh, disparity_min, knn2=kw.get("knn2")) for f in frames]
     pairs = []
     for p in range(len(frames) - 1):
         s = None if samples is None else samples[p]

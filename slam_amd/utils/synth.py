@@ -23,8 +23,16 @@ def random_descriptors(rng: np.random.Generator, n: int, nbytes: int = 61) -> np
 
 
 def flip_bits(rng: np.random.Generator, desc: np.ndarray, p: float) -> np.ndarray:
-    noise = np.packbits(rng.random((desc.shape[0], desc.shape[1] * 8)) < p, axis=1)
-    out = desc ^ noise
+    """Flip each bit independently with probability ~p (positions drawn with
+    replacement: a position drawn twice flips back, which is immaterial here)."""
+    out = np.ascontiguousarray(desc).copy()
+    total_bits = out.size * 8
+    if total_bits == 0 or p <= 0:
+        return out
+    k = int(rng.binomial(total_bits, p))
+    pos = rng.integers(0, total_bits, k)
+    flat = out.reshape(-1)
+    np.bitwise_xor.at(flat, pos >> 3, (1 << (pos & 7)).astype(np.uint8))
     if desc.shape[1] == 61:
         out[:, 60] &= 0x3F
     return out

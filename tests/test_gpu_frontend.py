@@ -108,3 +108,57 @@ def test_frontend_device_sampler_and_edge_cases():
     # single frame: stereo stage only
     r1 = fe.run(frames[:1])
     assert len(r1.frame(0)["left_idx"]) > 50
+
+
+def _shard_worker(rank, world, port, q):
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # both ranks share the one GPU
+    try:
+        from slam_amd.backend.tracking import sharding
+        from slam_amd.backend.tracking.frontend import TrackingFrontend
+        torch.cuda.set_device(0)
+        cam, seq, frames = _sequence(7, 400, seed=21)
+        n_iter = 256
+        rng = np.random.default_rng(9)
+        samples = rng.integers(0, 50, (len(frames) - 1, n_iter, 4)).astype(np.int32)
+        samples[..., 1] += 50; samples[..., 2] += 100; samples[..., 3] += 150   # distinct rows
+        fe = TrackingFrontend(cam, n_iter_max=n_iter)
+        merged = sharding.run_sharded(fe, frames, rank, world, samples=samples)
+        whole = sharding.run_sharded(fe, frames, 0, 1, samples=samples)
+        ok = True
+        for a, b in zip(merged["frames"], whole["frames"]):
+            for k in b:
+                ok = ok and np.array_equal(a[k], b[k])
+        for a, b in zip(merged["pairs"], whole["pairs"]):
+            for k in ("query_idx", "train_idx", "dist", "mask", "Rt", "Rt_ransac"):
+                ok = ok and np.array_equal(a[k], b[k])
+            ok = ok and a["best_index"] == b["best_index"] and a["iterations"] == b["iterations"]
+        ok = ok and merged["relative_Rts"].shape == (6, 3, 4)
+        q.put((rank, bool(ok)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_run_two_ranks_equals_single_rank():
+    """Frame-range sharding + gather (gloo here, RCCL on a multi-GPU node) gives
+    exactly the single-process result."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)], results
