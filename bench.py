@@ -79,7 +79,7 @@ def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 1.5):
     }, idx2, dist2
 
 
-def bench_frontend(args, rank, world, dist):
+def bench_frontend(args, rank, world, dist, red_dev="cuda"):
     """Secondary measurement (BASELINE configs[2]/[3] shape): the whole per-frame
     front-end (stereo match, filter, triangulate, temporal match, adaptive P3P
     RANSAC, LM refinement) over `--frames` synthetic KITTI-shaped frames per GPU,
@@ -102,10 +102,8 @@ def bench_frontend(args, rank, world, dist):
 
     def step():
         res = fe.run(inputs)
-        if dist is not None:
-            own_f = [res.frame(i) for i in range(F)]
-            own_p = [res.pair(i) for i in range(F - 1)]
-            blob = sharding.pack_records(own_f, own_p, rank * F, rank * (F - 1), 61)
+        if dist is not None:   # device-side record assembly + one all_gather
+            blob = sharding.pack_result(res, (0, F), (0, F - 1), rank * F, rank * (F - 1))
             sharding.all_gather_records(blob)
         return res
 
@@ -122,7 +120,7 @@ def bench_frontend(args, rank, world, dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank != 0:
@@ -197,13 +195,22 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU")
+    # Rehearsal knobs (one-GPU box): SLAMHIP_BENCH_BACKEND=gloo and
+    # SLAMHIP_BENCH_ONE_DEVICE=1 run all ranks on cuda:0 with a CPU-side barrier.
+    backend = os.environ.get("SLAMHIP_BENCH_BACKEND", "nccl")
+    if os.environ.get("SLAMHIP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from slam_amd import _lib, kernels
     from slam_amd.utils.synth import matcher_workload
@@ -217,8 +224,7 @@ def main():
     keep = torch.empty(NQ, dtype=torch.uint8, device=q.device)
 
     def step():
-        kernels.hamming_knn2(q, t, out=(idx2, dist2))
-        kernels.ratio_test(dist2, RATIO, out=keep)
+        kernels.hamming_knn2_ratio(q, t, RATIO, out=(idx2, dist2, keep))
         return idx2, dist2, keep
 
     def fence():
@@ -236,7 +242,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -254,7 +260,7 @@ def main():
 
     frontend = None
     if args.frames >= 2:
-        frontend = bench_frontend(args, rank, world, dist)
+        frontend = bench_frontend(args, rank, world, dist, red_dev)
 
     if rank == 0:
         compares = float(NQ) * NT

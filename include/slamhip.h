@@ -83,6 +83,14 @@ int slamhip_hamming_knn2(const uint8_t *d_query, int nq, const uint8_t *d_train,
                          int desc_bytes, int row_stride, int32_t *d_idx2, int32_t *d_dist2,
                          void *d_workspace, size_t workspace_bytes, void *stream);
 
+/* k=2 neighbours and the Lowe ratio test in one call (the ratio decision is
+ * taken where the split results are folded; same outputs as
+ * slamhip_hamming_knn2 followed by slamhip_ratio_test). */
+int slamhip_hamming_knn2_ratio(const uint8_t *d_query, int nq, const uint8_t *d_train, int nt,
+                               int desc_bytes, int row_stride, double ratio, int32_t *d_idx2,
+                               int32_t *d_dist2, uint8_t *d_keep, void *d_workspace,
+                               size_t workspace_bytes, void *stream);
+
 /* Batched form: n_pairs independent (query set, train set) problems in one
  * launch.  Pair p owns query rows [q_off[p], q_off[p+1]) and train rows
  * [t_off[p], t_off[p+1]) of the concatenated descriptor arrays; train indices

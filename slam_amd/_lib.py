@@ -49,6 +49,8 @@ SIGNATURES = {
     "slamhip_profile_end": (_i, [_dp]),
     "slamhip_hamming_knn2_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),
     "slamhip_hamming_knn2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "slamhip_hamming_knn2_ratio": (
+        _i, [_vp, _i, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
     "slamhip_hamming_knn2_batched": (
         _i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "slamhip_ratio_test": (_i, [_vp, _i, _d, _vp, _vp]),

@@ -5,21 +5,31 @@ Consecutive-frame pairs are independent (the pose of pair (k-1,k) needs only the
 features of frames k-1 and k; fill_database.py:140-240 of the reference), so
 rank r processes a contiguous range of pairs and re-computes the stereo stage
 of one halo frame.  There is no collective on the data path.  At the end every
-rank contributes one variable-length byte record (poses, links, inlier
-descriptors, temporal matches, masks - everything TrackingDB.add_frame and the
-bundle-adjustment back-end consume, run_slam.py:88-89) to ONE all_gather
-(RCCL over xGMI with the nccl backend; gloo on CPU for tests).
+rank contributes ONE variable-length byte record - poses, links, inlier
+descriptors, temporal matches, masks: everything TrackingDB.add_frame and the
+bundle-adjustment back-end consume (run_slam.py:88-89) - to one all_gather
+(RCCL over xGMI with the nccl backend; gloo on CPU for tests).  The record is
+assembled on the device (row compaction by index gathers), so with nccl the
+results never take a host hop before the collective.
+
+Record layout (little endian): int64 header [n_frames, n_pairs, first_frame,
+first_pair, desc_bytes], int64 stereo counts, int64 temporal counts, then the
+fields below, each flat over all owned frames / pairs.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Sequence, Tuple
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
+import torch
 
+# (name, numpy dtype, columns) in record order
 FRAME_FIELDS = (("left_idx", np.int32, 1), ("right_idx", np.int32, 1), ("dist", np.int32, 1),
-                ("xyz", np.float32, 3), ("pix_left", np.float32, 2), ("pix_right", np.float32, 2))
-PAIR_FIELDS = (("query_idx", np.int32, 1), ("train_idx", np.int32, 1), ("dist", np.int32, 1),
-               ("mask", np.uint8, 1))
+                ("xyz", np.float32, 3), ("pix_left", np.float32, 2), ("pix_right", np.float32, 2),
+                ("inlier_des_left", np.uint8, -1))          # -1: desc_bytes columns
+PAIR_ROW_FIELDS = (("query_idx", np.int32, 1), ("train_idx", np.int32, 1), ("dist", np.int32, 1),
+                   ("mask", np.uint8, 1))
+PAIR_FIXED_FIELDS = (("Rt", np.float64, 12), ("Rt_ransac", np.float64, 12), ("info", np.int32, 8))
 
 
 def pair_ranges(n_frames: int, world: int) -> List[Tuple[int, int]]:
@@ -35,136 +45,242 @@ def pair_ranges(n_frames: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
-def frames_for_rank(n_frames: int, world: int, rank: int) -> Tuple[int, int, Tuple[int, int], Tuple[int, int]]:
-    """(first_frame, last_frame_exclusive) this rank must load, the pair range it
-    owns, and the frame range whose stereo records it owns.  Frame f is owned by
-    the rank owning pair f; the final frame by the rank owning the last pair.
-    With a single frame (no pairs) rank 0 owns it."""
-    lo, hi = pair_ranges(n_frames, world)[rank]
+def frames_for_rank(n_frames: int, world: int, rank: int):
+    """((first_frame, last_frame_exclusive) to load, pair range owned, frame range
+    whose stereo records are owned).  Frame f is owned by the rank owning pair f;
+    the final frame by the rank owning the last pair.  With a single frame (no
+    pairs) rank 0 owns it."""
+    ranges = pair_ranges(n_frames, world)
+    lo, hi = ranges[rank]
     if n_frames == 1:
         return (0, 1, (0, 0), (0, 1)) if rank == 0 else (0, 0, (0, 0), (0, 0))
     if hi == lo:
         return lo, lo, (lo, hi), (lo, lo)
-    last_owner = max(r for r, (a, b) in enumerate(pair_ranges(n_frames, world)) if b > a)
+    last_owner = max(r for r, (a, b) in enumerate(ranges) if b > a)
     own_hi = hi + 1 if rank == last_owner else hi
     return lo, hi + 1, (lo, hi), (lo, own_hi)
 
 
+def _segment_rows(start: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
+    """Row indices start[i] .. start[i]+count[i]-1 for every segment i, in order."""
+    count = count.to(torch.int64)
+    total = int(count.sum().item())
+    if total == 0:
+        return torch.zeros(0, dtype=torch.int64, device=start.device)
+    first = torch.cumsum(count, 0) - count
+    seg = torch.repeat_interleave(torch.arange(count.numel(), device=start.device), count,
+                                  output_size=total)
+    return start.to(torch.int64)[seg] + (torch.arange(total, device=start.device) - first[seg])
+
+
+def pack_result(res, frame_range: Tuple[int, int], pair_range: Tuple[int, int], first_frame: int,
+                first_pair: int) -> torch.Tensor:
+    """Serialise the owned records of a FrontendResult into one uint8 tensor on
+    the result's device.  Ranges are local to the result's batch; first_frame /
+    first_pair are the global indices of the first owned frame / pair."""
+    t, inp = res.t, res.inputs
+    dev = t["st_count"].device
+    D, W = inp.desc_bytes, res.W
+    flo, fhi = frame_range
+    plo, phi = pair_range
+    off = inp.d_off_left.to(torch.int64)
+    st_cnt = t["st_count"][flo:fhi].to(torch.int64)
+    info = t["ransac_info"].reshape(-1, 8)
+    tm_cnt = info[plo:phi, 5].to(torch.int64)
+    frows = _segment_rows(off[flo:fhi], st_cnt)
+    prows = _segment_rows(off[plo:phi], tm_cnt)
+    head = torch.tensor([fhi - flo, phi - plo, first_frame, first_pair, D], dtype=torch.int64, device=dev)
+
+    def b(x):
+        return x.contiguous().reshape(-1).view(torch.uint8)
+
+    parts = [b(head), b(st_cnt), b(tm_cnt)]
+    parts += [b(t["st_left"][frows]), b(t["st_right"][frows]), b(t["st_dist"][frows]),
+              b(t["st_xyz"].reshape(-1, 3)[frows]), b(t["st_pix_left"].reshape(-1, 2)[frows]),
+              b(t["st_pix_right"].reshape(-1, 2)[frows]),
+              b(t["st_desc"].reshape(-1, W).view(torch.uint8).reshape(-1, W * 4)[frows][:, :D])]
+    parts += [b(t["tm_query"][prows]), b(t["tm_train"][prows]), b(t["tm_dist"][prows]),
+              b(t["tm_mask"][prows])]
+    parts += [b(t["pose_refined"].reshape(-1, 12)[plo:phi]), b(t["pose_ransac"].reshape(-1, 12)[plo:phi]),
+              b(info[plo:phi])]
+    return torch.cat(parts)
+
+
 def pack_records(frames: Sequence[dict], pairs: Sequence[dict], first_frame: int, first_pair: int,
                  desc_bytes: int) -> np.ndarray:
-    """Serialise owned per-frame / per-pair records into one uint8 array."""
-    head = [len(frames), len(pairs), first_frame, first_pair, desc_bytes]
-    head += [len(f["left_idx"]) for f in frames]
-    head += [len(p["query_idx"]) for p in pairs]
-    parts = [np.asarray(head, dtype=np.int64).view(np.uint8)]
-    for f in frames:
-        for name, dt, w in FRAME_FIELDS:
-            parts.append(np.ascontiguousarray(f[name], dtype=dt).reshape(-1).view(np.uint8))
-        parts.append(np.ascontiguousarray(f["inlier_des_left"], dtype=np.uint8).reshape(-1))
-    for p in pairs:
-        for name, dt, w in PAIR_FIELDS:
-            parts.append(np.ascontiguousarray(p[name], dtype=dt).reshape(-1).view(np.uint8))
-        parts.append(np.ascontiguousarray(p["Rt"], dtype=np.float64).reshape(-1).view(np.uint8))
-        parts.append(np.ascontiguousarray(p["Rt_ransac"], dtype=np.float64).reshape(-1).view(np.uint8))
-        parts.append(np.asarray([p["best_index"], p["best_count"], p["iterations"]],
-                                dtype=np.int64).view(np.uint8))
+    """Same record from per-frame / per-pair dicts (host); used by tests and by
+    callers that hold results in that form."""
+    head = np.array([len(frames), len(pairs), first_frame, first_pair, desc_bytes], dtype=np.int64)
+    st_cnt = np.array([len(f["left_idx"]) for f in frames], dtype=np.int64)
+    tm_cnt = np.array([len(p["query_idx"]) for p in pairs], dtype=np.int64)
+    parts = [head.view(np.uint8), st_cnt.view(np.uint8), tm_cnt.view(np.uint8)]
+    for name, dt, w in FRAME_FIELDS:
+        cols = desc_bytes if w < 0 else w
+        arrs = [np.asarray(f[name], dtype=dt).reshape(-1, cols) for f in frames]
+        cat = np.concatenate(arrs) if arrs else np.zeros((0, cols), dt)
+        parts.append(np.ascontiguousarray(cat).reshape(-1).view(np.uint8))
+    for name, dt, w in PAIR_ROW_FIELDS:
+        arrs = [np.asarray(p[name]).astype(dt).reshape(-1) for p in pairs]
+        cat = np.concatenate(arrs) if arrs else np.zeros(0, dt)
+        parts.append(np.ascontiguousarray(cat).view(np.uint8))
+    for name, dt, w in PAIR_FIXED_FIELDS:
+        if name == "info":
+            rows = [np.array([p["best_index"], p["best_count"], p["iterations"],
+                              p.get("n_iter_required", 0), int(p.get("domain_error", False)),
+                              len(p["query_idx"]), int(np.sum(p["mask"])), 0], dtype=dt) for p in pairs]
+        else:
+            rows = [np.asarray(p[name], dtype=dt).reshape(-1) for p in pairs]
+        cat = np.concatenate(rows) if rows else np.zeros(0, dt)
+        parts.append(np.ascontiguousarray(cat).view(np.uint8))
     return np.concatenate(parts)
 
 
-def unpack_records(blob: np.ndarray):
-    """Inverse of pack_records -> (first_frame, frames, first_pair, pairs)."""
+class SequenceResult:
+    """Flat per-sequence arrays + offsets; frame(f) / pair(p) give views shaped
+    like what the reference builds per frame."""
+
+    def __init__(self, n_frames: int, desc_bytes: int, st_cnt, tm_cnt, fields: Dict[str, np.ndarray]):
+        self.n_frames, self.desc_bytes = n_frames, desc_bytes
+        self.st_cnt, self.tm_cnt, self.f = st_cnt, tm_cnt, fields
+        self.st_off = np.concatenate([[0], np.cumsum(st_cnt)]).astype(np.int64)
+        self.tm_off = np.concatenate([[0], np.cumsum(tm_cnt)]).astype(np.int64)
+
+    def frame(self, f: int) -> dict:
+        sl = slice(int(self.st_off[f]), int(self.st_off[f + 1]))
+        out = {name: self.f[name][sl] for name, _, _ in FRAME_FIELDS}
+        pl, pr = out["pix_left"], out["pix_right"]
+        out["links"] = np.column_stack([pl[:, 0].astype(np.float64), pr[:, 0].astype(np.float64),
+                                        (pl[:, 1].astype(np.float64) + pr[:, 1].astype(np.float64)) / 2])
+        return out
+
+    def pair(self, p: int) -> dict:
+        sl = slice(int(self.tm_off[p]), int(self.tm_off[p + 1]))
+        info = self.f["info"][p]
+        return {"query_idx": self.f["tm_query_idx"][sl], "train_idx": self.f["tm_train_idx"][sl],
+                "dist": self.f["tm_dist"][sl], "mask": self.f["tm_mask"][sl].astype(bool),
+                "Rt": self.f["Rt"][p], "Rt_ransac": self.f["Rt_ransac"][p],
+                "best_index": int(info[0]), "best_count": int(info[1]), "iterations": int(info[2]),
+                "n_iter_required": int(info[3]), "domain_error": bool(info[4]),
+                "n_matches": int(self.tm_cnt[p])}
+
+    @property
+    def relative_Rts(self) -> np.ndarray:
+        """(n_frames-1,3,4): the array the reference pickles as `relative_Rts`."""
+        return self.f["Rt"]
+
+    @property
+    def frames(self):
+        return [self.frame(f) for f in range(self.n_frames)]
+
+    @property
+    def pairs(self):
+        return [self.pair(p) for p in range(max(self.n_frames - 1, 0))]
+
+
+def _parse(blob: np.ndarray):
     blob = np.ascontiguousarray(blob, dtype=np.uint8)
     pos = 0
 
     def take(dt, count):
         nonlocal pos
         nbytes = np.dtype(dt).itemsize * count
-        out = blob[pos:pos + nbytes].copy().view(dt)
+        if pos + nbytes > blob.size:
+            raise ValueError("truncated record")
+        out = blob[pos:pos + nbytes].view(dt)
         pos += nbytes
         return out
 
-    nf, npairs, first_frame, first_pair, desc_bytes = (int(v) for v in take(np.int64, 5))
-    fcounts = take(np.int64, nf)
-    pcounts = take(np.int64, npairs)
-    frames, pairs = [], []
-    for m in fcounts:
-        m = int(m)
-        f = {}
-        for name, dt, w in FRAME_FIELDS:
-            a = take(dt, m * w)
-            f[name] = a.reshape(m, w) if w > 1 else a
-        f["inlier_des_left"] = take(np.uint8, m * desc_bytes).reshape(m, desc_bytes)
-        frames.append(f)
-    for n in pcounts:
-        n = int(n)
-        p = {}
-        for name, dt, w in PAIR_FIELDS:
-            p[name] = take(dt, n)
-        p["mask"] = p["mask"].astype(bool)
-        p["Rt"] = take(np.float64, 12).reshape(3, 4)
-        p["Rt_ransac"] = take(np.float64, 12).reshape(3, 4)
-        bi, bc, it = (int(v) for v in take(np.int64, 3))
-        p.update(best_index=bi, best_count=bc, iterations=it, n_matches=n)
-        pairs.append(p)
-    return first_frame, frames, first_pair, pairs
+    nf, npairs, first_frame, first_pair, D = (int(v) for v in take(np.int64, 5))
+    st_cnt = take(np.int64, nf).copy()
+    tm_cnt = take(np.int64, npairs).copy()
+    ns, nt = int(st_cnt.sum()), int(tm_cnt.sum())
+    fields = {}
+    for name, dt, w in FRAME_FIELDS:
+        cols = D if w < 0 else w
+        a = take(dt, ns * cols)
+        fields[name] = a.reshape(ns, cols) if cols > 1 or w < 0 else a
+    for name, dt, w in PAIR_ROW_FIELDS:
+        fields["tm_" + name] = take(dt, nt)
+    for name, dt, w in PAIR_FIXED_FIELDS:
+        fields[name] = take(dt, npairs * w).reshape(npairs, w)
+    return first_frame, first_pair, D, st_cnt, tm_cnt, fields
 
 
-def all_gather_records(blob: np.ndarray, group=None, device=None) -> List[np.ndarray]:
+def merge_records(blobs: Sequence[np.ndarray], n_frames: int) -> SequenceResult:
+    """Reassemble the whole sequence from the per-rank records (any order)."""
+    parsed = [_parse(b) for b in blobs if b is not None and len(b) > 0]
+    parsed = [p for p in parsed if len(p[3]) or len(p[4])]
+    by_frame = sorted((p for p in parsed if len(p[3])), key=lambda p: p[0])
+    by_pair = sorted((p for p in parsed if len(p[4])), key=lambda p: p[1])
+    nf = sum(len(p[3]) for p in by_frame)
+    npairs = sum(len(p[4]) for p in by_pair)
+    exp_f = 0
+    for p in by_frame:
+        if p[0] != exp_f:
+            raise RuntimeError(f"frame records missing or duplicated at frame {exp_f}")
+        exp_f += len(p[3])
+    exp_p = 0
+    for p in by_pair:
+        if p[1] != exp_p:
+            raise RuntimeError(f"pair records missing or duplicated at pair {exp_p}")
+        exp_p += len(p[4])
+    if nf != n_frames or npairs != max(n_frames - 1, 0):
+        raise RuntimeError(f"gathered {nf} frames / {npairs} pairs, expected {n_frames} / {n_frames - 1}")
+    D = parsed[0][2] if parsed else 0
+    fields = {}
+    for name, dt, w in FRAME_FIELDS:
+        cols = D if w < 0 else w
+        arrs = [p[5][name] for p in by_frame]
+        fields[name] = np.concatenate(arrs) if arrs else np.zeros((0, cols) if cols > 1 or w < 0 else 0, dt)
+    for name, dt, w in PAIR_ROW_FIELDS:
+        arrs = [p[5]["tm_" + name] for p in by_pair]
+        fields["tm_" + name] = np.concatenate(arrs) if arrs else np.zeros(0, dt)
+    for name, dt, w in PAIR_FIXED_FIELDS:
+        arrs = [p[5][name] for p in by_pair]
+        fields[name] = np.concatenate(arrs) if arrs else np.zeros((0, w), dt)
+    fields["Rt"] = fields["Rt"].reshape(-1, 3, 4)
+    fields["Rt_ransac"] = fields["Rt_ransac"].reshape(-1, 3, 4)
+    st_cnt = np.concatenate([p[3] for p in by_frame]) if by_frame else np.zeros(0, np.int64)
+    tm_cnt = np.concatenate([p[4] for p in by_pair]) if by_pair else np.zeros(0, np.int64)
+    return SequenceResult(n_frames, D, st_cnt, tm_cnt, fields)
+
+
+def all_gather_records(blob, group=None) -> List[np.ndarray]:
     """One all_gather of variable-length byte records (padded to the longest).
-    Needs an initialised torch.distributed process group; `device` = 'cuda' for
-    the nccl (RCCL) backend, 'cpu' for gloo."""
-    import torch
+    `blob`: uint8 torch tensor (device tensor for nccl, CPU for gloo) or NumPy
+    array.  Returns every rank's record as NumPy arrays."""
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    if device is None:
-        device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
-    n = torch.tensor([blob.size], dtype=torch.int64, device=device)
+    device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    if not isinstance(blob, torch.Tensor):
+        blob = torch.from_numpy(np.ascontiguousarray(blob))
+    blob = blob.to(device)
+    n = torch.tensor([blob.numel()], dtype=torch.int64, device=device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(sizes, n, group=group)
     sizes = [int(s.item()) for s in sizes]
     cap = max(max(sizes), 1)
     buf = torch.zeros(cap, dtype=torch.uint8, device=device)
-    if blob.size:
-        buf[:blob.size] = torch.from_numpy(blob).to(device)
+    buf[:blob.numel()] = blob
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
     return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
 
 
-def merge_records(blobs: Sequence[np.ndarray], n_frames: int) -> Dict[str, list]:
-    """Reassemble the whole sequence: {'frames': [n_frames dicts], 'pairs':
-    [n_frames-1 dicts], 'relative_Rts': (n_frames-1,3,4)}."""
-    frames: List = [None] * n_frames
-    pairs: List = [None] * max(n_frames - 1, 0)
-    for blob in blobs:
-        if blob.size == 0:
-            continue
-        ff, fr, fp, pr = unpack_records(blob)
-        for i, f in enumerate(fr):
-            frames[ff + i] = f
-        for i, p in enumerate(pr):
-            pairs[fp + i] = p
-    missing = [i for i, f in enumerate(frames) if f is None] + [i for i, p in enumerate(pairs) if p is None]
-    if missing:
-        raise RuntimeError(f"records missing after gather: {missing[:8]}")
-    rel = np.stack([p["Rt"] for p in pairs]) if pairs else np.zeros((0, 3, 4))
-    return {"frames": frames, "pairs": pairs, "relative_Rts": rel}
-
-
-def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None, samples=None):
+def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
+                samples: Optional[np.ndarray] = None) -> SequenceResult:
     """Process this rank's share of `frames` on its GPU and gather everything.
-    Every rank returns the merged result (all_gather)."""
+    Every rank returns the merged result."""
     n_frames = len(frames)
     lo, hi, (plo, phi), (flo, fhi) = frames_for_rank(n_frames, world, rank)
     desc_bytes = int(np.asarray(frames[0][2]).shape[1])
-    own_frames, own_pairs = [], []
     if hi > lo:
         s = None if samples is None else samples[plo:phi]
         res = frontend.run(list(frames[lo:hi]), samples=s)
-        own_frames = [res.frame(f - lo) for f in range(flo, fhi)]
-        own_pairs = [res.pair(p - lo) for p in range(plo, phi)]
-    blob = pack_records(own_frames, own_pairs, flo, plo, desc_bytes)
+        blob = pack_result(res, (flo - lo, fhi - lo), (plo - lo, phi - lo), flo, plo)
+    else:
+        blob = torch.from_numpy(pack_records([], [], 0, 0, desc_bytes))
     if world == 1:
-        return merge_records([blob], n_frames)
+        return merge_records([blob.cpu().numpy()], n_frames)
     return merge_records(all_gather_records(blob, group), n_frames)

@@ -128,15 +128,40 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
       const uint4 *src = reinterpret_cast<const uint4 *>(tp + (size_t)(t0 + tile_begin) * W);
       for (int i = threadIdx.x; i < rows * (W / 4); i += kThreads) tile[i] = src[i];
       __syncthreads();
-      for (int jj = 0; jj < rows; ++jj) {
+      // wave-uniform trip count kept in an SGPR so the loop control stays off the VALU
+      const int rows_u = __builtin_amdgcn_readfirstlane(rows);
+      int jj = 0;
+      for (; jj + 2 <= rows_u; jj += 2) {
+        uint32_t ta[W], tb[W];
+#pragma unroll
+        for (int w4 = 0; w4 < W / 4; ++w4) {
+          const uint4 v = tile[jj * (W / 4) + w4];
+          ta[4 * w4 + 0] = v.x; ta[4 * w4 + 1] = v.y; ta[4 * w4 + 2] = v.z; ta[4 * w4 + 3] = v.w;
+        }
+#pragma unroll
+        for (int w4 = 0; w4 < W / 4; ++w4) {
+          const uint4 v = tile[(jj + 1) * (W / 4) + w4];
+          tb[4 * w4 + 0] = v.x; tb[4 * w4 + 1] = v.y; tb[4 * w4 + 2] = v.z; tb[4 * w4 + 3] = v.w;
+        }
+        const uint32_t jidx = (uint32_t)(tile_begin + jj);
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+          uint32_t acc = 0, acc2 = 0;
+#pragma unroll
+          for (int w = 0; w < W; ++w) {
+            acc += __builtin_popcount(ta[w] ^ qv[q][w]);
+            acc2 += __builtin_popcount(tb[w] ^ qv[q][w]);
+          }
+          top2_push(b1[q], b2[q], (acc << kKeyShift) | jidx);
+          top2_push(b1[q], b2[q], (acc2 << kKeyShift) | (jidx + 1u));
+        }
+      }
+      if (jj < rows_u) {
         uint32_t tw[W];
 #pragma unroll
         for (int w4 = 0; w4 < W / 4; ++w4) {
           const uint4 v = tile[jj * (W / 4) + w4];
-          tw[4 * w4 + 0] = v.x;
-          tw[4 * w4 + 1] = v.y;
-          tw[4 * w4 + 2] = v.z;
-          tw[4 * w4 + 3] = v.w;
+          tw[4 * w4 + 0] = v.x; tw[4 * w4 + 1] = v.y; tw[4 * w4 + 2] = v.z; tw[4 * w4 + 3] = v.w;
         }
         const uint32_t jidx = (uint32_t)(tile_begin + jj);
 #pragma unroll
@@ -192,17 +217,32 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
   }
 }
 
-// Folds the per-split key pairs.  One thread per query row; reads are
-// coalesced across rows for every split.
+// Folds the per-split key pairs.  Block = 64 query rows x 4 split groups: lane
+// (row, g) folds splits g, g+4, ... (coalesced over rows), the four groups meet
+// in LDS.  Optionally applies the ratio test to the final pair.
 __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restrict__ partial,
                                                             int nq_total, int n_splits,
                                                             int32_t *__restrict__ idx2,
-                                                            int32_t *__restrict__ dist2) {
-  const int row = blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= nq_total) return;
+                                                            int32_t *__restrict__ dist2,
+                                                            double ratio,
+                                                            uint8_t *__restrict__ keep) {
+  __shared__ uint2 part[4][64];
+  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int row = blockIdx.x * 64 + lane;
   uint32_t b1 = kNoKey, b2 = kNoKey;
-  for (int s = 0; s < n_splits; ++s) {
-    const uint2 p = partial[(size_t)s * nq_total + row];
+  if (row < nq_total) {
+    for (int s = g; s < n_splits; s += 4) {
+      const uint2 p = partial[(size_t)s * nq_total + row];
+      top2_push(b1, b2, p.x);
+      top2_push(b1, b2, p.y);
+    }
+  }
+  part[g][lane] = make_uint2(b1, b2);
+  __syncthreads();
+  if (g != 0 || row >= nq_total) return;
+#pragma unroll
+  for (int k = 1; k < 4; ++k) {
+    const uint2 p = part[k][lane];
     top2_push(b1, b2, p.x);
     top2_push(b1, b2, p.y);
   }
@@ -213,6 +253,8 @@ __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restr
   od.y = b2 == kNoKey ? -1 : (int32_t)(b2 >> kKeyShift);
   reinterpret_cast<int2 *>(idx2)[row] = oi;
   reinterpret_cast<int2 *>(dist2)[row] = od;
+  if (keep != nullptr)
+    keep[row] = (od.x >= 0 && od.y >= 0 && (double)od.x < ratio * (double)od.y) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void ratio_test_kernel(const int32_t *__restrict__ dist2, int nq,
@@ -366,7 +408,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
              int desc_bytes, int row_stride, const int32_t *d_q_off, const int32_t *d_t_off,
              int n_pairs, int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
              void *d_workspace, size_t workspace_bytes, void *stream, bool prepacked = false,
-             const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr) {
+             const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr,
+             uint8_t *d_keep = nullptr, double ratio = 0.0) {
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
     return SLAMHIP_EINVAL;
   if (desc_bytes < 1 || row_stride < desc_bytes) return SLAMHIP_EINVAL;
@@ -426,8 +469,12 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.splits > 1) {
-    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(nq_total, 256)), dim3(256), 0,
-                       st, part, nq_total, p.splits, d_idx2, d_dist2);
+    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(nq_total, 64)), dim3(256), 0,
+                       st, part, nq_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
+    SLAMHIP_CHECK_LAUNCH();
+  } else if (d_keep != nullptr) {
+    hipLaunchKernelGGL(ratio_test_kernel, dim3(slamhip_ceil_div(nq_total, 256)), dim3(256), 0, st,
+                       d_dist2, nq_total, ratio, d_keep);
     SLAMHIP_CHECK_LAUNCH();
   }
   return SLAMHIP_OK;
@@ -494,6 +541,17 @@ int slamhip_hamming_knn2(const uint8_t *d_query, int nq, const uint8_t *d_train,
   SLAMHIP_BEGIN();
   return run_knn2(d_query, nq, d_train, nt, desc_bytes, row_stride, nullptr, nullptr, 1, nq, nt,
                   d_idx2, d_dist2, d_workspace, workspace_bytes, stream);
+}
+
+int slamhip_hamming_knn2_ratio(const uint8_t *d_query, int nq, const uint8_t *d_train, int nt,
+                               int desc_bytes, int row_stride, double ratio, int32_t *d_idx2,
+                               int32_t *d_dist2, uint8_t *d_keep, void *d_workspace,
+                               size_t workspace_bytes, void *stream) {
+  SLAMHIP_BEGIN();
+  if (!d_keep && nq > 0) return SLAMHIP_EINVAL;
+  return run_knn2(d_query, nq, d_train, nt, desc_bytes, row_stride, nullptr, nullptr, 1, nq, nt,
+                  d_idx2, d_dist2, d_workspace, workspace_bytes, stream, false, nullptr, nullptr,
+                  d_keep, ratio);
 }
 
 int slamhip_hamming_knn2_batched(const uint8_t *d_query, int nq_total, const uint8_t *d_train,

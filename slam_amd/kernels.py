@@ -89,6 +89,29 @@ def hamming_knn2(q, t, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     return idx2, dist2
 
 
+def hamming_knn2_ratio(q, t, ratio: float, out=None):
+    """k=2 neighbours + ratio test in one call -> (idx2, dist2, keep)."""
+    q, t = _desc_pair(q, t)
+    nq, nt = q.shape[0], t.shape[0]
+    d = q.shape[1] if nq else (t.shape[1] if nt else 1)
+    if out is not None:
+        idx2, dist2, keep = out
+    else:
+        idx2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
+        dist2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
+        keep = torch.empty(nq, dtype=torch.uint8, device=q.device)
+    if nq == 0:
+        return idx2, dist2, keep
+    need = lib.slamhip_hamming_knn2_workspace_bytes(nq, nt, 1, nq, nt, d)
+    if need == 0:
+        check(_lib.EUNSUPPORTED, "slamhip_hamming_knn2_workspace_bytes")
+    ws = _workspace(need)
+    check(lib.slamhip_hamming_knn2_ratio(_ptr(q), nq, _ptr(t), nt, d, d, float(ratio), _ptr(idx2),
+                                         _ptr(dist2), _ptr(keep), _ptr(ws), ws.numel(), _stream()),
+          "slamhip_hamming_knn2_ratio")
+    return idx2, dist2, keep
+
+
 def hamming_knn2_batched(q, t, q_off, t_off, max_nq: Optional[int] = None,
                          max_nt: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """n_pairs independent problems in one launch; offsets are (n_pairs+1,)

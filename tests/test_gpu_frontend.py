@@ -129,14 +129,19 @@ def _shard_worker(rank, world, port, q):
         merged = sharding.run_sharded(fe, frames, rank, world, samples=samples)
         whole = sharding.run_sharded(fe, frames, 0, 1, samples=samples)
         ok = True
-        for a, b in zip(merged["frames"], whole["frames"]):
+        direct = fe.run(frames, samples=samples)          # no packing at all
+        for f, (a, b) in enumerate(zip(merged.frames, whole.frames)):
+            c = direct.frame(f)
             for k in b:
-                ok = ok and np.array_equal(a[k], b[k])
-        for a, b in zip(merged["pairs"], whole["pairs"]):
+                ok = ok and np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k])
+        for p, (a, b) in enumerate(zip(merged.pairs, whole.pairs)):
+            c = direct.pair(p)
             for k in ("query_idx", "train_idx", "dist", "mask", "Rt", "Rt_ransac"):
-                ok = ok and np.array_equal(a[k], b[k])
-            ok = ok and a["best_index"] == b["best_index"] and a["iterations"] == b["iterations"]
-        ok = ok and merged["relative_Rts"].shape == (6, 3, 4)
+                ok = ok and np.array_equal(a[k], b[k]) and np.array_equal(a[k], c[k])
+            ok = ok and a["best_index"] == b["best_index"] == c["best_index"]
+            ok = ok and a["iterations"] == b["iterations"] == c["iterations"]
+        ok = ok and merged.relative_Rts.shape == (6, 3, 4)
+        ok = ok and np.array_equal(merged.relative_Rts, direct.relative_Rts())
         q.put((rank, bool(ok)))
     except Exception as e:  # pragma: no cover
         import traceback

@@ -104,6 +104,13 @@ def test_ratio_test_and_sort_and_cross_check():
     for ratio in (0.5, 0.8, 0.99, 1.0):
         keep = kernels.ratio_test(d, ratio).cpu().numpy().astype(bool)
         np.testing.assert_array_equal(keep, so.ratio_test(d.cpu().numpy(), ratio))
+    for ratio in (0.7, 0.99):   # fused call = knn2 followed by ratio_test
+        fi, fd, fk = kernels.hamming_knn2_ratio(q, t, ratio)
+        np.testing.assert_array_equal(fi.cpu().numpy(), i.cpu().numpy())
+        np.testing.assert_array_equal(fd.cpu().numpy(), d.cpu().numpy())
+        np.testing.assert_array_equal(fk.cpu().numpy().astype(bool), so.ratio_test(d.cpu().numpy(), ratio))
+    fi, fd, fk = kernels.hamming_knn2_ratio(q[:100], t[:20], 0.8)   # single split: separate ratio pass
+    np.testing.assert_array_equal(fk.cpu().numpy().astype(bool), so.ratio_test(fd.cpu().numpy(), 0.8))
     order = kernels.sort_by_distance(d[:, 0].contiguous()).cpu().numpy()
     np.testing.assert_array_equal(order, so.sort_by_distance(d[:, 0].cpu().numpy()))
     order2 = kernels.sort_by_distance(d, stride=2).cpu().numpy()
