@@ -37,6 +37,12 @@ NQ = NT = 8192
 DESC_BYTES = 61
 RATIO = 0.8
 PEAK_LANE_OPS = 4 * 32 * 256 * 2.4e9      # int32 VALU lane-ops/s (MI355X, 2-cycle wave64 issue)
+# What the PMC counters show this chip doing for v_xor/v_bcnt: one wave64 VALU
+# instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle).
+MEASURED_ISSUE_LANE_OPS = 4 * 16 * 256 * 2.4e9
+# HBM-side bytes per top-2 launch from the committed PMC passes (profiles/r1/pmc_matcher8k.txt):
+# FETCH_SIZE 2327 KB x2 (gfx950 wide-read correction) + WRITE_SIZE 4096 KB.
+PMC_TRAFFIC_BYTES = (2327 * 2 + 4096) * 1024
 OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
 HBM_BYTES_PER_CALL = (NQ + NT) * DESC_BYTES + NQ * 16 + NQ   # read descriptors, write idx2/dist2/keep
 
@@ -102,9 +108,9 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
 
     def step():
         res = fe.run(inputs)
-        if dist is not None:   # device-side record assembly + one all_gather
+        if dist is not None:   # device-side record assembly + one gather onto rank 0's GPU
             blob = sharding.pack_result(res, (0, F), (0, F - 1), rank * F, rank * (F - 1))
-            sharding.all_gather_records(blob)
+            sharding.gather_records(blob, dst=0)
         return res
 
     for _ in range(2):
@@ -134,7 +140,8 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
         "ms_per_frame": elapsed / (F * args.frontend_steps) * 1e3,
         "workload": f"{F} synthetic KITTI-shaped stereo frames per GPU (1226x370, 1500 AKAZE-like "
                     f"features per image, 61-byte descriptors), full front-end per frame, features given"
-                    + ("" if world == 1 else "; per-frame records gathered once per pass (all_gather)"),
+                    + ("" if world == 1 else "; per-frame records (poses, links, inlier descriptors, "
+                       "matches, masks) packed on the device and gathered onto rank 0 once per pass"),
         "steps": args.frontend_steps,
         "stereo_inliers_mean": float(h["st_count"][:F].mean()),
         "temporal_matches_mean": float(info[:, 5].mean()),
@@ -287,8 +294,12 @@ def main():
                          "unit": "Tlane-op/s", "frac": achieved / PEAK_LANE_OPS,
                          "ops_per_compare": OPS_PER_COMPARE,
                          "kernel_us": kernel_s * 1e6, "launches_timed": n_launch,
+                         "frac_of_measured_issue_rate": achieved / MEASURED_ISSUE_LANE_OPS,
                          "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
-                         "traffic": None},
+                         "traffic": PMC_TRAFFIC_BYTES,
+                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes "
+                                         "(profiles/r1/pmc_matcher8k.txt); includes the 4 MB of "
+                                         "split results the kernel writes for the merge"},
         }
         if frontend is not None:
             line["frontend"] = frontend

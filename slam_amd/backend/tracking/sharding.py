@@ -268,10 +268,35 @@ def all_gather_records(blob, group=None) -> List[np.ndarray]:
     return [o[:s].cpu().numpy() for o, s in zip(out, sizes)]
 
 
+def gather_records(blob: torch.Tensor, dst: int = 0, group=None) -> Optional[List[torch.Tensor]]:
+    """Gather of the variable-length records onto rank `dst` only (the host of
+    the back-end): sizes by a tiny all_gather, payload by one gather of buffers
+    padded to the longest record.  Returns the list of records (uint8 tensors on
+    the collective's device, trimmed) on `dst`, None elsewhere."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    device = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    blob = blob.to(device)
+    n = torch.tensor([blob.numel()], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n, group=group)
+    sizes = [int(s.item()) for s in sizes]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros(cap, dtype=torch.uint8, device=device)
+    buf[:blob.numel()] = blob
+    out = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+    dist.gather(buf, out, dst=dst, group=group)
+    if rank != dst:
+        return None
+    return [o[:s] for o, s in zip(out, sizes)]
+
+
 def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
-                samples: Optional[np.ndarray] = None) -> SequenceResult:
-    """Process this rank's share of `frames` on its GPU and gather everything.
-    Every rank returns the merged result."""
+                samples: Optional[np.ndarray] = None, dst: int = 0) -> Optional[SequenceResult]:
+    """Process this rank's share of `frames` on its GPU and gather the records
+    on rank `dst`, which returns the merged result (other ranks return None)."""
     n_frames = len(frames)
     lo, hi, (plo, phi), (flo, fhi) = frames_for_rank(n_frames, world, rank)
     desc_bytes = int(np.asarray(frames[0][2]).shape[1])
@@ -283,4 +308,7 @@ def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
         blob = torch.from_numpy(pack_records([], [], 0, 0, desc_bytes))
     if world == 1:
         return merge_records([blob.cpu().numpy()], n_frames)
-    return merge_records(all_gather_records(blob, group), n_frames)
+    got = gather_records(blob, dst, group)
+    if got is None:
+        return None
+    return merge_records([g.cpu().numpy() for g in got], n_frames)

@@ -1,0 +1,75 @@
+"""CPU test of the hand-over to the reference's TrackingDB interface: shapes,
+ordering and the invariants TrackingDB.add_frame asserts
+(backend/tracking/database.py:319,327,332)."""
+import pickle
+
+import numpy as np
+
+from slam_amd.backend.tracking import db_adapter, sharding
+
+
+class RecordingDB:
+    """Checks what the reference's add_frame asserts and records the calls."""
+
+    def __init__(self):
+        self.calls = []
+        self.prev_features = None
+
+    def add_frame(self, links, left_features, matches_to_previous_left=None, inliers=None):
+        assert left_features.shape[0] == len(links)
+        if self.prev_features is None:
+            assert matches_to_previous_left is None
+        else:
+            assert matches_to_previous_left is not None
+            assert self.prev_features.shape[0] == len(matches_to_previous_left) == len(inliers)
+            for m, ok in zip(matches_to_previous_left, inliers):
+                assert 0 <= m.queryIdx < self.prev_features.shape[0]
+                assert 0 <= m.trainIdx < left_features.shape[0]
+        self.prev_features = left_features
+        self.calls.append((links, left_features, matches_to_previous_left, inliers))
+        return len(self.calls) - 1
+
+
+def _records(rng, n_frames):
+    frames, pairs = [], []
+    for f in range(n_frames):
+        m = int(rng.integers(5, 30))
+        frames.append({"left_idx": np.arange(m, dtype=np.int32), "right_idx": np.arange(m, dtype=np.int32),
+                       "dist": rng.integers(0, 99, m).astype(np.int32),
+                       "xyz": rng.normal(size=(m, 3)).astype(np.float32),
+                       "pix_left": rng.uniform(0, 1000, (m, 2)).astype(np.float32),
+                       "pix_right": rng.uniform(0, 1000, (m, 2)).astype(np.float32),
+                       "inlier_des_left": rng.integers(0, 256, (m, 61), dtype=np.uint8)})
+    for p in range(n_frames - 1):
+        n, mt = len(frames[p]["left_idx"]), len(frames[p + 1]["left_idx"])
+        pairs.append({"query_idx": rng.permutation(n).astype(np.int32),
+                      "train_idx": rng.integers(0, mt, n).astype(np.int32),
+                      "dist": np.sort(rng.integers(0, 200, n)).astype(np.int32),
+                      "mask": rng.random(n) < 0.6, "Rt": rng.normal(size=(3, 4)),
+                      "Rt_ransac": rng.normal(size=(3, 4)), "best_index": 3, "best_count": 7,
+                      "iterations": 11})
+    return frames, pairs
+
+
+def test_replay_into_db_and_relative_rts(tmp_path):
+    rng = np.random.default_rng(1)
+    frames, pairs = _records(rng, 5)
+    seq = sharding.merge_records([sharding.pack_records(frames, pairs, 0, 0, 61)], 5)
+    db = db_adapter.replay_into_db(RecordingDB(), seq)
+    assert len(db.calls) == 5
+    for f, (links, des, matches, inliers) in enumerate(db.calls):
+        np.testing.assert_array_equal(des, frames[f]["inlier_des_left"])
+        pl, pr = frames[f]["pix_left"], frames[f]["pix_right"]
+        assert [l.x_left for l in links] == [float(v) for v in pl[:, 0]]
+        assert [l.x_right for l in links] == [float(v) for v in pr[:, 0]]
+        assert [l.y for l in links] == [(float(a) + float(b)) / 2 for a, b in zip(pl[:, 1], pr[:, 1])]
+        if f > 0:
+            assert [m.queryIdx for m in matches] == pairs[f - 1]["query_idx"].tolist()
+            assert [m.distance for m in matches] == pairs[f - 1]["dist"].astype(float).tolist()
+            np.testing.assert_array_equal(inliers, pairs[f - 1]["mask"])
+    path = tmp_path / "relative_Rts"
+    rel = db_adapter.save_relative_Rts(seq, str(path))
+    with open(path, "rb") as fh:
+        back = pickle.load(fh)
+    np.testing.assert_array_equal(back, np.stack([p["Rt"] for p in pairs]))
+    assert rel.shape == (4, 3, 4)

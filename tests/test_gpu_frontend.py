@@ -127,6 +127,9 @@ def _shard_worker(rank, world, port, q):
         samples[..., 1] += 50; samples[..., 2] += 100; samples[..., 3] += 150   # distinct rows
         fe = TrackingFrontend(cam, n_iter_max=n_iter)
         merged = sharding.run_sharded(fe, frames, rank, world, samples=samples)
+        if rank != 0:
+            q.put((rank, merged is None))
+            return
         whole = sharding.run_sharded(fe, frames, 0, 1, samples=samples)
         ok = True
         direct = fe.run(frames, samples=samples)          # no packing at all

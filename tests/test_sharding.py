@@ -104,6 +104,13 @@ def _worker(rank, world, port, n_frames, q):
         for a, b in zip(merged.pairs, pairs):
             _same(a, b)
         ok = ok and np.array_equal(merged.relative_Rts, np.stack([p["Rt"] for p in pairs]))
+        # gather onto rank 0 only: same records, nothing returned elsewhere
+        got = sharding.gather_records(torch.from_numpy(blob), dst=0)
+        if rank == 0:
+            m2 = sharding.merge_records([g.numpy() for g in got], n_frames)
+            ok = ok and np.array_equal(m2.relative_Rts, merged.relative_Rts)
+        else:
+            ok = ok and got is None
         q.put((rank, bool(ok)))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))
