@@ -284,6 +284,51 @@ typedef struct slamhip_frontend_args {
 size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *args);
 int slamhip_frontend_batch(const slamhip_frontend_args *args, void *stream);
 
+/* ------------------------------------------------------------------------- */
+/* Pair verification: LoopClosure.consensus_pnp_match                        */
+/* (backend/optimizers/loop_closure.py:167-235) for a LIST of                */
+/* (candidate, current) keyframe pairs at once.                              */
+/*                                                                           */
+/* Per keyframe (loop_closure.py:152-164,179-180,237-249): left/right        */
+/* keypoints rebuilt from the stored links, (x_left,y) / (x_right,y), fp64;  */
+/* every stored feature is triangulated in fp64 and kept as float32 (:209).  */
+/* Per pair (:192-222): match candidate descriptors (query) against the      */
+/* current keyframe's (train), k=1, sorted by distance; P3D = candidate      */
+/* points by queryIdx, pixels of the current keyframe by trainIdx (float32); */
+/* pairs with fewer than min_points matches are not attempted (:206-207);    */
+/* adaptive P3P RANSAC with stereo consensus; LM refinement on the inliers.  */
+/* The caller applies the `mask.sum() < min_inliers` test (:218-219) to      */
+/* d_info[8p+6] and inverts the pose (:226-228).                             */
+/*                                                                           */
+/* Pair p reads query rows [d_qbase[p], +d_qcnt[p]) and train rows           */
+/* [d_tbase[p], +d_tcnt[p]) of the per-keyframe arrays; its per-match        */
+/* outputs are at d_obase[p] (the caller lays pairs out back to back:        */
+/* n_out_total = sum of d_qcnt).                                             */
+/* ------------------------------------------------------------------------- */
+typedef struct slamhip_verify_args {
+  int32_t n_rows_total;                  /* rows of the per-keyframe arrays */
+  int32_t desc_bytes, desc_stride;
+  int32_t n_pairs, n_out_total, max_q, max_t;
+  const double *d_kp_left, *d_kp_right;  /* (n_rows_total,2) fp64 */
+  const uint8_t *d_des;                  /* (n_rows_total,desc_stride) uint8 */
+  const int32_t *d_qbase, *d_qcnt, *d_tbase, *d_tcnt, *d_obase; /* n_pairs each (device) */
+  double K[9], M_right[12], P_left[12], P_right[12];   /* host values */
+  double ransac_thresh, p_success;
+  int32_t n_iter_max, min_points, refine_iters, reserved;
+  uint64_t seed;
+  /* outputs */
+  float *d_xyz;                          /* n_rows_total*3: keyframe points */
+  int32_t *d_tm_query, *d_tm_train, *d_tm_dist;   /* n_out_total: sorted matches */
+  uint8_t *d_tm_mask;                    /* n_out_total */
+  double *d_pose_ransac, *d_pose_refined;/* n_pairs*12 */
+  int32_t *d_info;                       /* n_pairs*8, as d_ransac_info above */
+  void *d_workspace;
+  size_t workspace_bytes;
+} slamhip_verify_args;
+
+size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *args);
+int slamhip_verify_pairs(const slamhip_verify_args *args, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -39,30 +39,23 @@ def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2, knn2=None):
             "pix_left": kp_l[qi], "pix_right": kp_r[ti]}
 
 
-def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
-                   p_success=0.99999, n_iter_max=2500, rng=None, knn2=None):
-    """fill_database.py:185-207 for one pair.  `samples` (n_iter,4) fixes the
-    idx4 sequence (else rng.choice as in pnp.py:126); `solver(obj4,img4)` is the
-    minimal solver (default: oracle P3P)."""
-    qi, ti, di = _bf_match(prev["inlier_des_left"], curr["inlier_des_left"], knn2)  # :185
-    if len(curr["inlier_des_left"]) == 0:
-        qi, ti, di = qi[:0], ti[:0], di[:0]
-    X_corr = prev["xyz"][qi]                                                      # :189-190
-    pix_L, pix_R = curr["pix_left"][ti], curr["pix_right"][ti]                    # :195-197
+def ransac_loop(cam, X_corr, pix_L, pix_R, pixel_thresh, samples=None, solver=None,
+                p_success=0.99999, n_iter_max=2500, rng=None):
+    """PnP.ransac_pnp_pair1 (frontend/geometry/pnp.py:102-160), one iteration at
+    a time.  `samples` (n_iter,4) fixes the idx4 sequence (else rng.choice as in
+    pnp.py:126); `solver(obj4,img4)` is the minimal solver (default: oracle P3P)."""
+    import math
     N = len(X_corr)
-    out = {"query_idx": qi, "train_idx": ti, "dist": di, "n_matches": N, "X_corr": X_corr,
-           "pix_L": pix_L, "pix_R": pix_R, "mask": np.zeros(N, bool), "best_index": -1,
-           "best_count": 0, "iterations": 0, "Rt_ransac": None, "hyps": []}
+    out = {"mask": np.zeros(N, bool), "best_index": -1, "best_count": 0, "iterations": 0,
+           "Rt_ransac": None, "hyps": [], "n_iter_required": n_iter_max}
     if N < 4:
         return out
     if solver is None:
         solver = lambda o, i: so.p3p_solve(o, i, cam.K)
     if rng is None:
         rng = np.random.default_rng()
-    # pnp.py:110-160, one iteration at a time
     best_mask, best_count, best_idx, best_Rt = None, 0, -1, None
     iter_done, n_req = 0, n_iter_max
-    import math
     while iter_done < n_req and iter_done < n_iter_max:
         idx4 = samples[iter_done] if samples is not None else rng.choice(N, 4, replace=False)
         it = iter_done
@@ -83,6 +76,21 @@ def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
     return out
 
 
+def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
+                   p_success=0.99999, n_iter_max=2500, rng=None, knn2=None):
+    """fill_database.py:185-207 for one pair."""
+    qi, ti, di = _bf_match(prev["inlier_des_left"], curr["inlier_des_left"], knn2)  # :185
+    if len(curr["inlier_des_left"]) == 0:
+        qi, ti, di = qi[:0], ti[:0], di[:0]
+    X_corr = prev["xyz"][qi]                                                      # :189-190
+    pix_L, pix_R = curr["pix_left"][ti], curr["pix_right"][ti]                    # :195-197
+    out = {"query_idx": qi, "train_idx": ti, "dist": di, "n_matches": len(X_corr), "X_corr": X_corr,
+           "pix_L": pix_L, "pix_R": pix_R}
+    out.update(ransac_loop(cam, X_corr, pix_L, pix_R, pixel_thresh, samples, solver, p_success,
+                           n_iter_max, rng))
+    return out
+
+
 def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=True, **kw):
     stereo = [stereo_stage(cam, f, pixel_thresh, disparity_min, knn2=kw.get("knn2")) for f in frames]
     pairs = []
@@ -93,3 +101,31 @@ def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=T
             t["Rt"], _ = so.refine_pose(t["X_corr"], t["pix_L"], cam.K, t["Rt_ransac"], t["mask"])
         pairs.append(t)
     return stereo, pairs
+
+
+def consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loop=60,
+                        p_success=0.99999, n_iter_max=1500, rng=None, knn2=None, refine=True):
+    """LoopClosure.consensus_pnp_match (backend/optimizers/loop_closure.py:167-235)
+    up to the refined pose.  kf = (links (n,3) [x_left, x_right, y], des_left)."""
+    links_i, des_i = kf_cand
+    links_n, des_n = kf_curr
+    kpL_i, kpR_i = links_i[:, [0, 2]], links_i[:, [1, 2]]              # frame_data, :152-164
+    kpL_n, kpR_n = links_n[:, [0, 2]], links_n[:, [1, 2]]
+    obj = so.triangulate_cv(cam.P_left, cam.P_right, kpL_i, kpR_i, out_fp64=True)   # :179-180
+    qi, ti, di = _bf_match(des_i, des_n, knn2)                          # :192-195
+    out = {"query_idx": qi, "train_idx": ti, "dist": di, "obj": obj, "ok": False, "Rt": None,
+           "mask": np.zeros(len(qi), bool)}
+    if len(qi) < min_inliers_loop:                                      # :206-207
+        return out
+    P3D = obj[qi].astype(np.float32)                                    # :209
+    ptsL = kpL_n[ti].astype(np.float32)
+    ptsR = kpR_n[ti].astype(np.float32)
+    out.update(P3D=P3D, ptsL=ptsL, ptsR=ptsR)
+    r = ransac_loop(cam, P3D, ptsL, ptsR, pixel_thresh, None, None, p_success, n_iter_max, rng)  # :215-216
+    out.update(r)
+    if r["mask"].sum() < min_inliers_loop:                              # :218-219
+        return out
+    if refine:
+        out["Rt"], _ = so.refine_pose(P3D, ptsL, cam.K, r["Rt_ransac"], r["mask"])   # :222
+    out["ok"] = True
+    return out

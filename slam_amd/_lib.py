@@ -89,6 +89,26 @@ class FrontendArgs(C.Structure):
     ]
 
 
+class VerifyArgs(C.Structure):
+    """Mirror of `slamhip_verify_args` (include/slamhip.h), field for field."""
+    _fields_ = [
+        ("n_rows_total", _i32), ("desc_bytes", _i32), ("desc_stride", _i32),
+        ("n_pairs", _i32), ("n_out_total", _i32), ("max_q", _i32), ("max_t", _i32),
+        ("d_kp_left", _vp), ("d_kp_right", _vp), ("d_des", _vp),
+        ("d_qbase", _vp), ("d_qcnt", _vp), ("d_tbase", _vp), ("d_tcnt", _vp), ("d_obase", _vp),
+        ("K", C.c_double * 9), ("M_right", C.c_double * 12),
+        ("P_left", C.c_double * 12), ("P_right", C.c_double * 12),
+        ("ransac_thresh", _d), ("p_success", _d),
+        ("n_iter_max", _i32), ("min_points", _i32), ("refine_iters", _i32), ("reserved", _i32),
+        ("seed", _u64),
+        ("d_xyz", _vp), ("d_tm_query", _vp), ("d_tm_train", _vp), ("d_tm_dist", _vp),
+        ("d_tm_mask", _vp), ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_info", _vp),
+        ("d_workspace", _vp), ("workspace_bytes", _sz),
+    ]
+
+
+SIGNATURES["slamhip_verify_workspace_bytes"] = (_sz, [C.POINTER(VerifyArgs)])
+SIGNATURES["slamhip_verify_pairs"] = (_i, [C.POINTER(VerifyArgs), _vp])
 SIGNATURES["slamhip_frontend_workspace_bytes"] = (_sz, [C.POINTER(FrontendArgs)])
 SIGNATURES["slamhip_frontend_batch"] = (_i, [C.POINTER(FrontendArgs), _vp])
 

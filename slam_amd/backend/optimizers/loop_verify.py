@@ -1,0 +1,122 @@
+"""Loop-closure candidate verification for many keyframe pairs at once: the
+arithmetic of LoopClosure.consensus_pnp_match
+(backend/optimizers/loop_closure.py:167-235 of the reference) executed by
+`slamhip_verify_pairs`.  The pose-graph / GTSAM side of loop closure stays in
+the reference; this class produces what it consumes per verified pair: success
+flag, relative pose, inlier mask and the matches.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ... import _lib, kernels
+from ..._lib import lib, check, VerifyArgs
+
+
+class PairVerifier:
+    """Defaults follow the reference: PnP pixel threshold 1.5 px and
+    min_inliers_loop (loop_closure.py:24-32), p_success 0.99999 and
+    n_iter_max 1500 (loop_closure.py:215-216)."""
+
+    def __init__(self, cam, pixel_thresh: float = 1.5, min_inliers_loop: int = 60,
+                 p_success: float = 0.99999, n_iter_max: int = 1500, refine_iters: int = 30,
+                 seed: int = 0):
+        self.cam = cam
+        self.pixel_thresh, self.min_inliers = float(pixel_thresh), int(min_inliers_loop)
+        self.p_success, self.n_iter_max = float(p_success), int(n_iter_max)
+        self.refine_iters, self.seed = int(refine_iters), int(seed)
+        self._kf = None
+        self._ws = None
+
+    def set_keyframes(self, keyframes: Sequence[Tuple[np.ndarray, np.ndarray]]):
+        """keyframes[i] = (links (n,3) float64 rows [x_left, x_right, y], des_left (n,D) uint8):
+        what LoopClosure.frame_data reads back from the TrackingDB."""
+        n = [len(k[0]) for k in keyframes]
+        for links, des in keyframes:
+            if len(links) != len(des):
+                raise ValueError("links and descriptors differ in length")
+        off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        links = np.concatenate([np.asarray(k[0], dtype=np.float64).reshape(-1, 3) for k in keyframes])
+        des = np.concatenate([np.asarray(k[1], dtype=np.uint8) for k in keyframes])
+        kp_l = np.ascontiguousarray(links[:, [0, 2]])
+        kp_r = np.ascontiguousarray(links[:, [1, 2]])
+        self._kf = {"n": np.asarray(n, dtype=np.int64), "off": off,
+                    "kp_l": kernels.to_device(kp_l, torch.float64),
+                    "kp_r": kernels.to_device(kp_r, torch.float64),
+                    "des": kernels.to_device(des, torch.uint8)}
+        return self
+
+    def verify(self, pairs) -> dict:
+        """pairs: (P,2) int array of (candidate, current) keyframe indices.
+        Returns a dict of host arrays: ok (P,), Rt (P,3,4) candidate->current
+        pose, Rt_ransac, n_matches, n_inliers, iterations, out_off (P+1,), and the
+        flat per-match arrays query_idx / train_idx / dist / mask."""
+        if self._kf is None:
+            raise RuntimeError("call set_keyframes first")
+        kf = self._kf
+        pairs = np.asarray(pairs, dtype=np.int64).reshape(-1, 2)
+        P = len(pairs)
+        cand, curr = pairs[:, 0], pairs[:, 1]
+        qcnt, tcnt = kf["n"][cand], kf["n"][curr]
+        obase = np.concatenate([[0], np.cumsum(qcnt)])
+        O, N = int(obase[-1]), int(kf["off"][-1])
+        if O >= 2 ** 31 or N >= 2 ** 31:
+            raise ValueError("too many rows for 32-bit offsets; split the pair list")
+        dev = kf["des"].device
+        i32 = lambda a: kernels.to_device(np.ascontiguousarray(a, dtype=np.int32), torch.int32)
+        d_qbase, d_qcnt = i32(kf["off"][cand]), i32(qcnt)
+        d_tbase, d_tcnt, d_obase = i32(kf["off"][curr]), i32(tcnt), i32(obase[:-1])
+        out = {
+            "xyz": torch.empty(max(N, 1) * 3, dtype=torch.float32, device=dev),
+            "tm_query": torch.empty(max(O, 1), dtype=torch.int32, device=dev),
+            "tm_train": torch.empty(max(O, 1), dtype=torch.int32, device=dev),
+            "tm_dist": torch.empty(max(O, 1), dtype=torch.int32, device=dev),
+            "tm_mask": torch.zeros(max(O, 1), dtype=torch.uint8, device=dev),
+            "pose_ransac": torch.zeros(max(P, 1) * 12, dtype=torch.float64, device=dev),
+            "pose_refined": torch.zeros(max(P, 1) * 12, dtype=torch.float64, device=dev),
+            "info": torch.zeros(max(P, 1) * 8, dtype=torch.int32, device=dev),
+        }
+        a = VerifyArgs()
+        a.n_rows_total, a.n_pairs, a.n_out_total = N, P, O
+        a.desc_bytes = a.desc_stride = int(kf["des"].shape[1])
+        a.max_q = int(qcnt.max()) if P else 0
+        a.max_t = int(tcnt.max()) if P else 0
+        a.d_kp_left, a.d_kp_right, a.d_des = kf["kp_l"].data_ptr(), kf["kp_r"].data_ptr(), kf["des"].data_ptr()
+        a.d_qbase, a.d_qcnt = d_qbase.data_ptr(), d_qcnt.data_ptr()
+        a.d_tbase, a.d_tcnt, a.d_obase = d_tbase.data_ptr(), d_tcnt.data_ptr(), d_obase.data_ptr()
+        for name, src, n in (("K", self.cam.K, 9), ("M_right", self.cam.M_right, 12),
+                             ("P_left", self.cam.P_left, 12), ("P_right", self.cam.P_right, 12)):
+            setattr(a, name, (C.c_double * n)(*np.asarray(src, dtype=np.float64).reshape(-1).tolist()))
+        a.ransac_thresh, a.p_success = self.pixel_thresh, self.p_success
+        a.n_iter_max, a.min_points, a.refine_iters = self.n_iter_max, self.min_inliers, self.refine_iters
+        a.seed = self.seed
+        a.d_xyz = out["xyz"].data_ptr()
+        a.d_tm_query, a.d_tm_train = out["tm_query"].data_ptr(), out["tm_train"].data_ptr()
+        a.d_tm_dist, a.d_tm_mask = out["tm_dist"].data_ptr(), out["tm_mask"].data_ptr()
+        a.d_pose_ransac, a.d_pose_refined = out["pose_ransac"].data_ptr(), out["pose_refined"].data_ptr()
+        a.d_info = out["info"].data_ptr()
+        need = lib.slamhip_verify_workspace_bytes(C.byref(a))
+        if need == 0:
+            check(_lib.EUNSUPPORTED, "slamhip_verify_workspace_bytes")
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.d_workspace, a.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        check(lib.slamhip_verify_pairs(C.byref(a), torch.cuda.current_stream().cuda_stream),
+              "slamhip_verify_pairs")
+        self.last_device_outputs = out
+        torch.cuda.synchronize()
+        info = out["info"].cpu().numpy().reshape(-1, 8)[:P]
+        n_matches, n_inl = info[:, 5], info[:, 6]
+        ok = (n_matches >= self.min_inliers) & (n_inl >= self.min_inliers) & (info[:, 0] >= 0)
+        return {
+            "ok": ok, "Rt": out["pose_refined"].cpu().numpy().reshape(-1, 3, 4)[:P],
+            "Rt_ransac": out["pose_ransac"].cpu().numpy().reshape(-1, 3, 4)[:P],
+            "n_matches": n_matches, "n_inliers": n_inl, "iterations": info[:, 2],
+            "out_off": obase, "xyz": out["xyz"].cpu().numpy().reshape(-1, 3)[:N],
+            "query_idx": out["tm_query"].cpu().numpy()[:O], "train_idx": out["tm_train"].cpu().numpy()[:O],
+            "dist": out["tm_dist"].cpu().numpy()[:O], "mask": out["tm_mask"].cpu().numpy()[:O].astype(bool),
+        }

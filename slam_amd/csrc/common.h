@@ -29,15 +29,18 @@ static inline int slamhip_packed_words(int desc_bytes) {
 // Cross-translation-unit entry points (not part of the C ABI).
 namespace slamhip_internal {
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
-                            int desc_bytes);
+                            int desc_bytes, long long n_out = -1, bool prepacked = false);
 // Batched top-2 matcher.  prepacked: rows are already W-dword packed (row_stride
 // = 4*W, 16-byte aligned).  Pair p owns query rows [q_off[p], q_off[p] + count)
 // with count = q_cnt[p] (or q_off[p+1]-q_off[p] when q_cnt is NULL); same for t.
+// d_out_off != NULL: the result of query row r of pair p is written at output row
+// d_out_off[p] + r of idx2/dist2, which then hold n_out_total rows (the same
+// query set may take part in many pairs).
 int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total, int desc_bytes,
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
-         hipStream_t st);
+         hipStream_t st, const int32_t *d_out_off = nullptr, int n_out_total = -1);
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,

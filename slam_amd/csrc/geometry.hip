@@ -46,10 +46,11 @@ __global__ __launch_bounds__(256) void filter_triangulate_kernel(
   if (ok) {
     double x[4];
     dlt_null_vector(cam, uL, vL, uR, vR, x);
-    if (out_fp64) {
+    if (out_fp64) {  // 1: fp64 out; 2: fp64 division, result stored as fp32
       X = x[0] / x[3];
       Y = x[1] / x[3];
       Z = x[2] / x[3];
+      Xf = (float)X; Yf = (float)Y; Zf = (float)Z;
     } else {
       const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
       Xf = x0 / x3;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void filter_triangulate_kernel(
       Zf = x2 / x3;
     }
   }
-  if (out_fp64) {
+  if (out_fp64 == 1) {
     double *o = reinterpret_cast<double *>(xyz) + 3 * (size_t)k;
     o[0] = X; o[1] = Y; o[2] = Z;
   } else {

@@ -77,9 +77,9 @@ template <int W, int Q, bool USE_LDS>
 __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
-    const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt, int nq_single,
-    int nt_single, int nq_total, uint2 *__restrict__ partial, int32_t *__restrict__ idx2,
-    int32_t *__restrict__ dist2) {
+    const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
+    const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
+    uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2) {
   const int pair = blockIdx.z;
   int q0 = 0, nq = nq_single, t0 = 0, nt = nt_single;
   if (q_off != nullptr) {
@@ -88,6 +88,9 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
     t0 = t_off[pair];
     nt = t_cnt ? t_cnt[pair] : t_off[pair + 1] - t0;
   }
+  // results of query row r of this pair go to output row o0 + r (default: the
+  // query's own global row); nq_total is the number of output rows
+  const int o0 = out_off ? out_off[pair] : q0;
   const int qblk = blockIdx.x * (kThreads * Q);
   if (qblk >= nq) return;  // block-uniform
 
@@ -205,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
     if (qrow[q] >= nq) continue;
-    const size_t row = (size_t)(q0 + qrow[q]);
+    const size_t row = (size_t)(o0 + qrow[q]);
     if (n_splits == 1) {
       idx2[2 * row + 0] = b1[q] == kNoKey ? -1 : (int32_t)(b1[q] & kIdxMask);
       idx2[2 * row + 1] = b2[q] == kNoKey ? -1 : (int32_t)(b2[q] & kIdxMask);
@@ -362,7 +365,8 @@ int g_force_variant = -1;  // diagnostics: -1 auto, bit0 = LDS, bits 1.. = Q
 int g_force_splits = 0;
 
 MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
-                    int desc_bytes) {
+                    int desc_bytes, long long n_out = -1, bool prepacked = false) {
+  if (n_out < 0) n_out = nq_total;
   MatchPlan p;
   p.W = slamhip_packed_words(desc_bytes);
   // Measured on MI355X (8192x8192x61 B): LDS-staged tile, one query per lane is
@@ -386,11 +390,11 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   p.splits = (int)s;
   size_t o = 0;
   p.off_qp = o;
-  o = slamhip_align_up(o + (size_t)nq_total * p.W * 4, 256);
+  if (!prepacked) o = slamhip_align_up(o + (size_t)nq_total * p.W * 4, 256);
   p.off_tp = o;
-  o = slamhip_align_up(o + (size_t)nt_total * p.W * 4, 256);
+  if (!prepacked) o = slamhip_align_up(o + (size_t)nt_total * p.W * 4, 256);
   p.off_part = o;
-  o = slamhip_align_up(o + (size_t)kMaxSplits * nq_total * sizeof(uint2), 256);
+  if (p.splits > 1) o = slamhip_align_up(o + (size_t)p.splits * (size_t)n_out * sizeof(uint2), 256);
   p.total = o + 256;
   return p;
 }
@@ -398,10 +402,10 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
 template <int W, int Q, bool L>
 void launch_top2(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp,
                  const int32_t *q_off, const int32_t *q_cnt, const int32_t *t_off,
-                 const int32_t *t_cnt, int nq, int nt, int nq_total, uint2 *part, int32_t *idx2,
-                 int32_t *dist2) {
+                 const int32_t *t_cnt, const int32_t *out_off, int nq, int nt, int nq_total,
+                 uint2 *part, int32_t *idx2, int32_t *dist2) {
   hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L>), grid, dim3(kThreads), 0, st, qp, tp, q_off,
-                     q_cnt, t_off, t_cnt, nq, nt, nq_total, part, idx2, dist2);
+                     q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2);
 }
 
 int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total,
@@ -409,7 +413,9 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
              int n_pairs, int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
              void *d_workspace, size_t workspace_bytes, void *stream, bool prepacked = false,
              const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr,
-             uint8_t *d_keep = nullptr, double ratio = 0.0) {
+             uint8_t *d_keep = nullptr, double ratio = 0.0, const int32_t *d_out_off = nullptr,
+             int n_out_total = -1) {
+  if (n_out_total < 0) n_out_total = nq_total;
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
     return SLAMHIP_EINVAL;
   if (desc_bytes < 1 || row_stride < desc_bytes) return SLAMHIP_EINVAL;
@@ -421,7 +427,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   if (!d_query || !d_idx2 || !d_dist2 || (nt_total > 0 && !d_train)) return SLAMHIP_EINVAL;
   if (n_pairs > 1 && (!d_q_off || !d_t_off)) return SLAMHIP_EINVAL;
   if (max_nq == 0) return SLAMHIP_OK;
-  const MatchPlan p = make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes);
+  const MatchPlan p =
+      make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out_total, prepacked);
   if (!d_workspace || workspace_bytes < p.total) return SLAMHIP_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
@@ -453,8 +460,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   }
   const int nqs = d_q_off ? 0 : nq_total, nts = d_q_off ? 0 : nt_total;
 #define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
-  launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, nqs, nts, nq_total, \
-                          part, d_idx2, d_dist2)
+  launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, d_out_off, nqs, nts, \
+                          n_out_total, part, d_idx2, d_dist2)
   if (p.W == 8) {
     if (p.Q == 2) { if (p.use_lds) SLAMHIP_DISPATCH(8, 2, true); else SLAMHIP_DISPATCH(8, 2, false); }
     else          { if (p.use_lds) SLAMHIP_DISPATCH(8, 1, true); else SLAMHIP_DISPATCH(8, 1, false); }
@@ -469,12 +476,12 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.splits > 1) {
-    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(nq_total, 64)), dim3(256), 0,
-                       st, part, nq_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
+    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(n_out_total, 64)), dim3(256), 0,
+                       st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
     SLAMHIP_CHECK_LAUNCH();
   } else if (d_keep != nullptr) {
-    hipLaunchKernelGGL(ratio_test_kernel, dim3(slamhip_ceil_div(nq_total, 256)), dim3(256), 0, st,
-                       d_dist2, nq_total, ratio, d_keep);
+    hipLaunchKernelGGL(ratio_test_kernel, dim3(slamhip_ceil_div(n_out_total, 256)), dim3(256), 0, st,
+                       d_dist2, n_out_total, ratio, d_keep);
     SLAMHIP_CHECK_LAUNCH();
   }
   return SLAMHIP_OK;
@@ -613,18 +620,18 @@ int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total
 namespace slamhip_internal {
 
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
-                            int desc_bytes) {
-  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes).total;
+                            int desc_bytes, long long n_out, bool prepacked) {
+  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out, prepacked).total;
 }
 
 int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total, int desc_bytes,
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
-         hipStream_t st) {
+         hipStream_t st, const int32_t *d_out_off, int n_out_total) {
   return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
                   n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, (void *)st,
-                  prepacked, d_q_cnt, d_t_cnt);
+                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total);
 }
 
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,

@@ -108,32 +108,37 @@ __global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
 // --------------------------------------------------------------------------
 // Temporal stage: sorted matches -> 3D-2D correspondences of each pair.
 // --------------------------------------------------------------------------
+// Pair p matches the rows [qbase[p], +qcnt[p]) (query side: 3-D points) against
+// the rows [tbase[p], +tcnt[p]) (train side: pixels); its outputs live at
+// obase[p] of the pair-output arrays.
+template <typename PIX>
 __global__ __launch_bounds__(kBlock) void temporal_gather_kernel(
-    const int32_t *__restrict__ off_left, const int32_t *__restrict__ st_count,
-    const int32_t *__restrict__ tidx2, const int32_t *__restrict__ tdist2,
-    const int32_t *__restrict__ order2, const float *__restrict__ st_xyz,
-    const float *__restrict__ st_pix_left, const float *__restrict__ st_pix_right,
-    int32_t *__restrict__ tm_query, int32_t *__restrict__ tm_train, int32_t *__restrict__ tm_dist,
-    int32_t *__restrict__ tm_count, float *__restrict__ cx, float *__restrict__ cpl,
-    float *__restrict__ cpr) {
+    const int32_t *__restrict__ qbase, const int32_t *__restrict__ qcnt,
+    const int32_t *__restrict__ tbase, const int32_t *__restrict__ tcnt,
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tidx2,
+    const int32_t *__restrict__ tdist2, const int32_t *__restrict__ order2,
+    const float *__restrict__ xyz, const PIX *__restrict__ pix_left,
+    const PIX *__restrict__ pix_right, int32_t *__restrict__ tm_query,
+    int32_t *__restrict__ tm_train, int32_t *__restrict__ tm_dist, int32_t *__restrict__ tm_count,
+    float *__restrict__ cx, float *__restrict__ cpl, float *__restrict__ cpr) {
   const int p = blockIdx.y;
-  const int base = off_left[p], cbase = off_left[p + 1];
-  const int n = st_count[p + 1] > 0 ? st_count[p] : 0;  // no train rows -> no matches
+  const int qb = qbase[p], tb = tbase[p], ob = obase[p];
+  const int n = tcnt[p] > 0 ? qcnt[p] : 0;  // no train rows -> no matches
   if (blockIdx.x == 0 && threadIdx.x == 0) tm_count[p] = n;
   const int r = blockIdx.x * kBlock + (int)threadIdx.x;
   if (r >= n) return;
-  const int q = order2[base + r];
-  const int t = tidx2[2 * (size_t)(base + q)];
-  const size_t o = (size_t)(base + r);
+  const int q = order2[ob + r];
+  const int t = tidx2[2 * (size_t)(ob + q)];
+  const size_t o = (size_t)(ob + r);
   tm_query[o] = q;
   tm_train[o] = t;
-  tm_dist[o] = tdist2[2 * (size_t)(base + q)];
+  tm_dist[o] = tdist2[2 * (size_t)(ob + q)];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) cx[3 * o + c] = st_xyz[3 * (size_t)(base + q) + c];
+  for (int c = 0; c < 3; ++c) cx[3 * o + c] = xyz[3 * (size_t)(qb + q) + c];
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    cpl[2 * o + c] = st_pix_left[2 * (size_t)(cbase + t) + c];
-    cpr[2 * o + c] = st_pix_right[2 * (size_t)(cbase + t) + c];
+    cpl[2 * o + c] = (float)pix_left[2 * (size_t)(tb + t) + c];
+    cpr[2 * o + c] = (float)pix_right[2 * (size_t)(tb + t) + c];
   }
 }
 
@@ -155,11 +160,12 @@ struct RansacParams {
   Kinv kinv;
   double thresh, p_success;
   int n_iter_max;
+  int min_points;  // pairs with fewer correspondences are not attempted
   unsigned long long seed;
 };
 
 __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
-    const int32_t *__restrict__ off_left, const int32_t *__restrict__ tm_count,
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ pose_ransac,
     uint8_t *__restrict__ tm_mask, int32_t *__restrict__ info) {
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
   __shared__ double best_rt[12];
   __shared__ int st[8];  // best_count, best_idx, iter_done, n_req, stop, winner_lane, domain, mask_count
   const int p = blockIdx.x;
-  const int base = off_left[p];
+  const int base = obase[p];
   const int n = tm_count[p];
   const float *X = cx + 3 * (size_t)base;
   const float *mL = cpl + 2 * (size_t)base;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
   const double thr2 = prm.thresh * prm.thresh;
   const double log1mp = log(1.0 - prm.p_success);
 
-  if (n >= 4) {
+  if (n >= 4 && n >= prm.min_points) {
     for (int round = 0;; ++round) {
       const int it = round * kBlock + (int)threadIdx.x;
       const bool active = it < prm.n_iter_max;
@@ -425,10 +431,11 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   rc = slamhip_internal::sort_by_distance(tdist2, 2, a->d_off_left, a->d_st_count, F - 1, a->max_left,
                                           order2, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(temporal_gather_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F - 1),
-                     dim3(kBlock), 0, st, a->d_off_left, a->d_st_count, tidx2, tdist2, order2,
-                     a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_tm_query, a->d_tm_train,
-                     a->d_tm_dist, tcount, cx, cpl, cpr);
+  hipLaunchKernelGGL(temporal_gather_kernel<float>,
+                     dim3(slamhip_ceil_div(a->max_left, kBlock), F - 1), dim3(kBlock), 0, st,
+                     a->d_off_left, a->d_st_count, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left,
+                     tidx2, tdist2, order2, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right,
+                     a->d_tm_query, a->d_tm_train, a->d_tm_dist, tcount, cx, cpl, cpr);
   SLAMHIP_CHECK_LAUNCH();
 
   RansacParams prm;
@@ -438,6 +445,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   prm.thresh = a->ransac_thresh;
   prm.p_success = a->p_success;
   prm.n_iter_max = a->n_iter_max;
+  prm.min_points = 4;
   prm.seed = a->seed;
   hipLaunchKernelGGL(ransac_pairs_kernel, dim3(F - 1), dim3(kBlock), 0, st, a->d_off_left, tcount, cx,
                      cpl, cpr, a->d_samples, prm, a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info);
@@ -446,6 +454,111 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, a->d_off_left, tcount, F - 1, a->K,
                                      a->d_pose_ransac, a->refine_iters, a->d_pose_refined, nullptr, st);
   return rc;
+}
+
+// ---------------------------------------------------------------------------
+// Pair verification (loop-closure candidates).
+// ---------------------------------------------------------------------------
+size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
+  if (!a || a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0 || a->desc_bytes < 1 ||
+      a->desc_bytes > SLAMHIP_MAX_DESC_BYTES)
+    return 0;
+  const int W = slamhip_packed_words(a->desc_bytes);
+  const size_t N = (size_t)a->n_rows_total, O = (size_t)a->n_out_total;
+  const int chunk = a->n_pairs < 32768 ? (a->n_pairs > 0 ? a->n_pairs : 1) : 32768;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { o = slamhip_align_up(o + bytes, 256); };
+  take(N * W * 4);            // packed descriptors
+  take(O * 8); take(O * 8);   // idx2, dist2
+  take(O * 4);                // order
+  take(O * 12); take(O * 8); take(O * 8);  // cx, cpl, cpr
+  take((size_t)(a->n_pairs > 0 ? a->n_pairs : 1) * 4);  // counts
+  take(slamhip_internal::knn2_workspace_bytes(a->n_rows_total, a->n_rows_total, chunk, a->max_q,
+                                              a->max_t, a->desc_bytes, (long long)a->n_out_total,
+                                              true));
+  return o + 256;
+}
+
+int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
+  SLAMHIP_BEGIN();
+  if (!a || a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0) return SLAMHIP_EINVAL;
+  if (a->desc_bytes < 1 || a->desc_stride < a->desc_bytes || a->n_iter_max < 1 ||
+      a->refine_iters < 0 || a->max_q < 0 || a->max_t < 0)
+    return SLAMHIP_EINVAL;
+  if (a->desc_bytes > SLAMHIP_MAX_DESC_BYTES || a->max_q > SLAMHIP_MAX_TRAIN_ROWS ||
+      a->max_t > SLAMHIP_MAX_TRAIN_ROWS)
+    return SLAMHIP_EUNSUPPORTED;
+  if (a->n_rows_total == 0) return SLAMHIP_OK;
+  if (!a->d_kp_left || !a->d_kp_right || !a->d_des || !a->d_xyz) return SLAMHIP_EINVAL;
+  const size_t need = slamhip_verify_workspace_bytes(a);
+  if (!a->d_workspace || a->workspace_bytes < need) return SLAMHIP_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int W = slamhip_packed_words(a->desc_bytes);
+  const size_t N = (size_t)a->n_rows_total, O = (size_t)a->n_out_total;
+  uintptr_t cur = ((uintptr_t)a->d_workspace + 255) & ~(uintptr_t)255;
+  auto take = [&](size_t bytes) { const uintptr_t at = cur; cur = slamhip_align_up(cur + bytes, 256); return at; };
+  uint32_t *packed = (uint32_t *)take(N * W * 4);
+  int32_t *idx2 = (int32_t *)take(O * 8), *dist2 = (int32_t *)take(O * 8);
+  int32_t *order = (int32_t *)take(O * 4);
+  float *cx = (float *)take(O * 12), *cpl = (float *)take(O * 8), *cpr = (float *)take(O * 8);
+  int32_t *tcount = (int32_t *)take((size_t)(a->n_pairs > 0 ? a->n_pairs : 1) * 4);
+  const int chunk_max = a->n_pairs < 32768 ? (a->n_pairs > 0 ? a->n_pairs : 1) : 32768;
+  const size_t knn_bytes = slamhip_internal::knn2_workspace_bytes(
+      a->n_rows_total, a->n_rows_total, chunk_max, a->max_q, a->max_t, a->desc_bytes,
+      (long long)a->n_out_total, true);
+  void *knn_ws = (void *)take(knn_bytes);
+
+  // per keyframe: points of all stored features (loop_closure.py:179-180,237-249: fp64
+  // triangulation, later cast to float32 at :209) and packed descriptors
+  int rc = slamhip_stereo_filter_triangulate(a->d_kp_left, a->d_kp_right, 1, nullptr, nullptr,
+                                             a->n_rows_total, a->P_left, a->P_right, 0.0, 0.0,
+                                             nullptr, a->d_xyz, 2, stream);
+  if (rc) return rc;
+  rc = slamhip_internal::pack_rows(a->d_des, a->n_rows_total, packed, nullptr, 0, nullptr,
+                                   a->desc_bytes, a->desc_stride, st);
+  if (rc) return rc;
+  if (a->n_pairs == 0 || a->n_out_total == 0) return SLAMHIP_OK;
+  if (!a->d_qbase || !a->d_qcnt || !a->d_tbase || !a->d_tcnt || !a->d_obase || !a->d_tm_query ||
+      !a->d_tm_train || !a->d_tm_dist || !a->d_tm_mask || !a->d_pose_ransac || !a->d_pose_refined ||
+      !a->d_info)
+    return SLAMHIP_EINVAL;
+
+  RansacParams prm;
+  for (int i = 0; i < 9; ++i) prm.cam.K[i] = a->K[i];
+  for (int i = 0; i < 12; ++i) prm.cam.MR[i] = a->M_right[i];
+  if (!invert3x3(a->K, prm.kinv.m)) return SLAMHIP_EINVAL;
+  prm.thresh = a->ransac_thresh;
+  prm.p_success = a->p_success;
+  prm.n_iter_max = a->n_iter_max;
+  prm.min_points = a->min_points;
+
+  for (int c0 = 0; c0 < a->n_pairs; c0 += chunk_max) {
+    const int np = a->n_pairs - c0 < chunk_max ? a->n_pairs - c0 : chunk_max;
+    const int32_t *qb = a->d_qbase + c0, *qc = a->d_qcnt + c0, *tb = a->d_tbase + c0,
+                  *tc = a->d_tcnt + c0, *ob = a->d_obase + c0;
+    rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
+                                a->n_rows_total, a->desc_bytes, W * 4, true, qb, qc, tb, tc, np,
+                                a->max_q, a->max_t, idx2, dist2, knn_ws, knn_bytes, st, ob,
+                                a->n_out_total);
+    if (rc) return rc;
+    rc = slamhip_internal::sort_by_distance(dist2, 2, ob, qc, np, a->max_q, order, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(temporal_gather_kernel<double>, dim3(slamhip_ceil_div(a->max_q, kBlock), np),
+                       dim3(kBlock), 0, st, qb, qc, tb, tc, ob, idx2, dist2, order,
+                       (const float *)a->d_xyz, a->d_kp_left, a->d_kp_right, a->d_tm_query,
+                       a->d_tm_train, a->d_tm_dist, tcount + c0, cx, cpl, cpr);
+    SLAMHIP_CHECK_LAUNCH();
+    prm.seed = a->seed + (unsigned long long)c0 * 0x9E3779B97F4A7C15ull;
+    hipLaunchKernelGGL(ransac_pairs_kernel, dim3(np), dim3(kBlock), 0, st, ob, tcount + c0, cx, cpl,
+                       cpr, (const int32_t *)nullptr, prm, a->d_pose_ransac + 12 * (size_t)c0,
+                       a->d_tm_mask, a->d_info + 8 * (size_t)c0);
+    SLAMHIP_CHECK_LAUNCH();
+    rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, ob, tcount + c0, np, a->K,
+                                       a->d_pose_ransac + 12 * (size_t)c0, a->refine_iters,
+                                       a->d_pose_refined + 12 * (size_t)c0, nullptr, st);
+    if (rc) return rc;
+  }
+  return SLAMHIP_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,75 @@
+"""GPU test of loop-closure pair verification against the CPU restatement of
+LoopClosure.consensus_pnp_match."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline_oracle as po
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def test_verify_pairs_against_oracle():
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=120, n_features=900, seed=5, clutter=0.3)
+    kf_ids = [0, 2, 4, 60, 62, 118]
+    keyframes = []
+    for k in kf_ids:
+        f = seq.frame(k)
+        st = po.stereo_stage(cam, (f.kp_left, f.kp_right, f.des_left, f.des_right))
+        pl, pr = st["pix_left"].astype(np.float64), st["pix_right"].astype(np.float64)
+        links = np.column_stack([pl[:, 0], pr[:, 0], (pl[:, 1] + pr[:, 1]) / 2])   # Link(x_l, x_r, y)
+        keyframes.append((links, st["inlier_des_left"]))
+    pairs = np.array([(i, n) for n in range(len(kf_ids)) for i in range(n)], dtype=np.int64)
+    ver = PairVerifier(cam, seed=3).set_keyframes(keyframes)
+    res = ver.verify(pairs)
+    off = np.concatenate([[0], np.cumsum([len(k[0]) for k in keyframes])])
+    n_ok = 0
+    for p, (i, n) in enumerate(pairs):
+        ref = po.consensus_pnp_match(cam, keyframes[i], keyframes[n], rng=np.random.default_rng(p))
+        sl = slice(int(res["out_off"][p]), int(res["out_off"][p + 1]))
+        np.testing.assert_array_equal(res["query_idx"][sl], ref["query_idx"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(res["train_idx"][sl], ref["train_idx"])
+        np.testing.assert_array_equal(res["dist"][sl], ref["dist"])
+        xyz = res["xyz"][off[i]:off[i + 1]]
+        obj32 = ref["obj"].astype(np.float32)
+        assert np.abs(xyz - obj32).max() <= 2e-6 * np.abs(obj32).max()
+        assert bool(res["ok"][p]) == bool(ref["ok"]), (p, i, n, res["n_inliers"][p], ref.get("best_count"))
+        if not res["ok"][p]:
+            continue
+        n_ok += 1
+        # mask = reference formula on the device's own winner; pose = LS minimum on that mask
+        eL, eR = so.hypothesis_errors(cam.K, cam.M_right, res["Rt_ransac"][p], ref["P3D"], ref["ptsL"], ref["ptsR"])
+        refmask = (eL <= 1.5) & (eR <= 1.5)
+        bad = np.flatnonzero(refmask != res["mask"][sl])
+        assert all(min(abs(eL[k] - 1.5), abs(eR[k] - 1.5)) < 1e-6 for k in bad)
+        assert res["n_inliers"][p] == res["mask"][sl].sum()
+        gold, _ = so.refine_pose(ref["P3D"], ref["ptsL"], cam.K, res["Rt_ransac"][p], res["mask"][sl])
+        assert np.abs(res["Rt"][p] - gold).max() < 1e-7
+        # both estimate the same motion (different random samples, same consensus set up to a few points)
+        assert np.abs(res["Rt"][p] - ref["Rt"]).max() < 0.1
+        A = np.vstack([seq.poses[kf_ids[i]], [0, 0, 0, 1]])
+        B = np.vstack([seq.poses[kf_ids[n]], [0, 0, 0, 1]])
+        truth = (B @ np.linalg.inv(A))[:3]
+        assert np.abs(res["Rt"][p][:, 3] - truth[:, 3]).max() < 0.25
+    assert 3 <= n_ok < len(pairs)          # near keyframes verify, far ones do not
+
+
+def test_verify_pairs_edge_cases():
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(0)
+    def kf(n):
+        x = rng.uniform(100, 1000, n); y = rng.uniform(10, 300, n)
+        return (np.column_stack([x, x - rng.uniform(2, 50, n), y]), rng.integers(0, 256, (n, 61), dtype=np.uint8))
+    ver = PairVerifier(cam).set_keyframes([kf(10), kf(0), kf(80)])
+    res = ver.verify([(0, 2), (1, 2), (2, 1), (2, 0)])
+    assert not res["ok"].any()
+    assert res["n_matches"].tolist() == [10, 0, 0, 80]
+    assert res["iterations"][0] == 0          # fewer than min_inliers_loop matches: not attempted
+    assert ver.verify(np.zeros((0, 2), int))["ok"].shape == (0,)
