@@ -156,6 +156,57 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
     return out
 
 
+def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
+    """Secondary measurement (BASELINE configs[4] shape): descriptor matching +
+    PnP-RANSAC consensus + refinement for ALL pairs of `--lc-keyframes` synthetic
+    keyframes (one every ~14 m like the reference's keyframe rule), pair list
+    dealt round-robin over the ranks, no collective on the data path."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+
+    cam = CameraModel.kitti_like()
+    KF, step_frames = args.lc_keyframes, 17
+    seq = StereoSequence(cam, n_frames=KF * step_frames, n_features=1500, seed=7, clutter=0.6)
+    frames = []
+    for k in range(KF):
+        f = seq.frame(k * step_frames)
+        frames.append((f.kp_left, f.kp_right, f.des_left, f.des_right))
+    st = TrackingFrontend(cam, n_iter_max=1).run(frames)      # stereo stage gives the DB content
+    keyframes = []
+    for k in range(KF):
+        fr = st.frame(k)
+        keyframes.append((fr["links"], fr["inlier_des_left"]))
+    pairs = np.array([(i, n) for n in range(KF) for i in range(n)], dtype=np.int64)[rank::world]
+    ver = PairVerifier(cam, seed=rank).set_keyframes(keyframes)
+    ver.verify(pairs[:64])                                      # warm-up
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    res = ver.verify(pairs)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    n_pairs_total = KF * (KF - 1) // 2
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return None
+    return {"metric": "loop_closure_pairs_verified_per_sec", "value": n_pairs_total / elapsed,
+            "unit": "pairs/s", "seconds": elapsed, "keyframes": KF, "pairs": n_pairs_total,
+            "features_per_keyframe_mean": float(np.mean([len(k[0]) for k in keyframes])),
+            "verified_on_rank0": int(res["ok"].sum()), "pairs_on_rank0": int(len(pairs)),
+            "ransac_iterations_mean_rank0": float(res["iterations"].mean()),
+            "workload": "all-pairs keyframe verification (match k=1 + sort, P3P RANSAC <=1500 iters at "
+                        "1.5 px with stereo consensus, LM refinement), results copied to the host; "
+                        "time includes the per-call H2D of the pair tables and D2H of the results"}
+
+
 def cpu_baseline_frontend(cam, frames):
     """Frame-at-a-time CPU restatement (oracle/pipeline_oracle.py: NumPy geometry,
     C/OpenMP matcher, one RANSAC iteration at a time like pnp.py:123-158)."""
@@ -192,6 +243,8 @@ def main():
     ap.add_argument("--frames", type=int, default=500,
                     help="frames per GPU of the secondary front-end measurement (0 = skip)")
     ap.add_argument("--frontend-steps", type=int, default=5)
+    ap.add_argument("--lc-keyframes", type=int, default=270,
+                    help="keyframes of the secondary loop-closure verification measurement (0 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -269,6 +322,10 @@ def main():
     if args.frames >= 2:
         frontend = bench_frontend(args, rank, world, dist, red_dev)
 
+    loop_verify = None
+    if args.lc_keyframes >= 2:
+        loop_verify = bench_loop_verify(args, rank, world, dist, red_dev)
+
     if rank == 0:
         compares = float(NQ) * NT
         achieved = compares * OPS_PER_COMPARE / kernel_s
@@ -303,6 +360,8 @@ def main():
         }
         if frontend is not None:
             line["frontend"] = frontend
+        if loop_verify is not None:
+            line["loop_verify"] = loop_verify
         if world == 1 and not args.no_cpu_baseline:
             res = cpu_baseline(q_np, t_np)
             if res is not None:

@@ -90,11 +90,14 @@ class StereoSequence:
         self.land_xyz = np.column_stack([rng.uniform(-25, 25, n_land), rng.uniform(-3, 2, n_land),
                                          rng.uniform(2, length, n_land)])
         self.land_des = random_descriptors(rng, n_land, nbytes)
+        # heading = bounded weave (+-3 deg, 200-frame period) plus jitter, so the rig
+        # stays inside the landmark corridor however long the sequence is
         self.poses = []
-        R, pos = np.eye(3), np.zeros(3)
+        pos = np.zeros(3)
+        jitter = np.deg2rad(rng.uniform(-0.3, 0.3, n_frames))
         for k in range(n_frames):
+            R = _yaw(np.deg2rad(3.0) * np.sin(2 * np.pi * k / 200.0) + jitter[k])
             self.poses.append(np.hstack([R.T, (-R.T @ pos)[:, None]]))  # world -> camera
-            R = R @ _yaw(np.deg2rad(rng.uniform(-1.0, 1.0)))
             pos = pos + R @ np.array([0.0, 0.0, 0.8])
 
     def frame(self, k: int) -> StereoFrame:
