@@ -86,7 +86,7 @@ def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 1.5):
 
 
 def bench_frontend(args, rank, world, dist, red_dev="cuda"):
-    """Secondary measurement (BASELINE configs[2]/[3] shape): the whole per-frame
+    """Secondary measurement (BASELINE.json configs[2]/[3] shape): the whole per-frame
     front-end (stereo match, filter, triangulate, temporal match, adaptive P3P
     RANSAC, LM refinement) over `--frames` synthetic KITTI-shaped frames per GPU,
     features resident in HBM.  With N > 1 every rank processes its own frame
@@ -157,7 +157,7 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
 
 
 def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
-    """Secondary measurement (BASELINE configs[4] shape): descriptor matching +
+    """Secondary measurement (BASELINE.json configs[4] shape): descriptor matching +
     PnP-RANSAC consensus + refinement for ALL pairs of `--lc-keyframes` synthetic
     keyframes (one every ~14 m like the reference's keyframe rule), pair list
     dealt round-robin over the ranks, no collective on the data path."""

@@ -50,23 +50,28 @@ __device__ __forceinline__ void top2_push(uint32_t &b1, uint32_t &b2, uint32_t k
 __global__ __launch_bounds__(256) void pack_rows_kernel(
     const uint8_t *__restrict__ src_a, int n_a, uint32_t *__restrict__ dst_a,
     const uint8_t *__restrict__ src_b, int n_b, uint32_t *__restrict__ dst_b, int desc_bytes,
-    int stride, int W) {
-  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long total_a = (long long)n_a * W;
-  const long long total = total_a + (long long)n_b * W;
+    int stride, int log2W) {
+  // one thread per packed dword; W is a power of two, so row/word come from shifts
+  const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned total_a = (unsigned)n_a << log2W;
+  const unsigned total = total_a + ((unsigned)n_b << log2W);
   if (gid >= total) return;
-  const uint8_t *src;
-  uint32_t *dst;
-  long long g;
-  if (gid < total_a) { src = src_a; dst = dst_a; g = gid; }
-  else { src = src_b; dst = dst_b; g = gid - total_a; }
-  const long long r = g / W;
-  const int w = (int)(g - r * W);
-  const uint8_t *p = src + r * (long long)stride + 4 * w;
+  const bool first = gid < total_a;
+  const uint8_t *src = first ? src_a : src_b;
+  uint32_t *dst = first ? dst_a : dst_b;
+  const unsigned g = first ? gid : gid - total_a;
+  const unsigned r = g >> log2W;
+  const int w = (int)(g & ((1u << log2W) - 1u));
+  const uint8_t *p = src + (size_t)r * (size_t)stride + 4 * w;
+  const int valid = desc_bytes - 4 * w;  // bytes of this dword that belong to the row
   uint32_t v = 0;
+  if (valid >= 4 && (((uintptr_t)p) & 3u) == 0) {
+    v = *reinterpret_cast<const uint32_t *>(p);
+  } else {
 #pragma unroll
-  for (int b = 0; b < 4; ++b)
-    if (4 * w + b < desc_bytes) v |= (uint32_t)p[b] << (8 * b);
+    for (int b = 0; b < 4; ++b)
+      if (b < valid) v |= (uint32_t)p[b] << (8 * b);
+  }
   dst[g] = v;
 }
 
@@ -446,9 +451,10 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     tp = (uint32_t *)d_train;
   } else {
     const long long total = ((long long)nq_total + nt_total) * p.W;
+    if (total >= (1ll << 32)) return SLAMHIP_EUNSUPPORTED;
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, d_query, nq_total, qp,
-                       d_train, nt_total, tp, desc_bytes, row_stride, p.W);
+                       d_train, nt_total, tp, desc_bytes, row_stride, p.W == 8 ? 3 : (p.W == 16 ? 4 : 5));
     SLAMHIP_CHECK_LAUNCH();
   }
 
@@ -639,8 +645,10 @@ int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b
   const int W = slamhip_packed_words(desc_bytes);
   const long long total = ((long long)n_a + n_b) * W;
   if (total == 0) return SLAMHIP_OK;
+  if (total >= (1ll << 32)) return SLAMHIP_EUNSUPPORTED;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_a,
-                     n_a, d_dst_a, d_b, n_b, d_dst_b, desc_bytes, row_stride, W);
+                     n_a, d_dst_a, d_b, n_b, d_dst_b, desc_bytes, row_stride,
+                     W == 8 ? 3 : (W == 16 ? 4 : 5));
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

@@ -7,23 +7,31 @@ namespace slamhip_dev {
 
 struct Kinv { double m[9]; };
 
-__device__ __forceinline__ double horner(const double *c, int deg, double x) {
-  double r = c[deg];
-  for (int i = deg - 1; i >= 0; --i) r = fma(r, x, c[i]);
+// Polynomials are fixed-size register arrays (c[0] + c[1] x + ... + c[DEG] x^DEG)
+// and every loop over them is fully unrolled, so nothing here is indexed at
+// run time and nothing goes to scratch memory.
+template <int DEG>
+__device__ __forceinline__ double horner(const double (&c)[DEG + 1], double x) {
+  double r = c[DEG];
+#pragma unroll
+  for (int i = DEG - 1; i >= 0; --i) r = fma(r, x, c[i]);
   return r;
 }
 
-// Root of polynomial c (degree deg) inside [lo, hi] given a sign change; bisection
-// with Newton acceleration, always kept inside the bracket.
-__device__ double bracketed_root(const double *c, int deg, double lo, double hi, double flo) {
-  double d[4];
-  for (int i = 1; i <= deg; ++i) d[i - 1] = c[i] * (double)i;
+// Root of c inside [lo, hi] given a sign change; bisection with Newton
+// acceleration, always kept inside the bracket.
+template <int DEG>
+__device__ __forceinline__ double bracketed_root(const double (&c)[DEG + 1], double lo, double hi,
+                                                 double flo) {
+  double d[DEG];
+#pragma unroll
+  for (int i = 1; i <= DEG; ++i) d[i - 1] = c[i] * (double)i;
   double x = 0.5 * (lo + hi);
   for (int it = 0; it < 64; ++it) {
-    const double fx = horner(c, deg, x);
+    const double fx = horner<DEG>(c, x);
     if (fx == 0.0) return x;
     if ((fx < 0.0) == (flo < 0.0)) lo = x; else hi = x;
-    const double dfx = horner(d, deg - 1, x);
+    const double dfx = horner<DEG - 1>(d, x);
     double xn = x - fx / dfx;
     if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
     if (fabs(xn - x) <= 4.4e-16 * fmax(1.0, fabs(xn))) return xn;
@@ -32,41 +40,62 @@ __device__ double bracketed_root(const double *c, int deg, double lo, double hi,
   return x;
 }
 
-// Real roots of c[0] + c[1] x + ... + c[deg] x^deg (deg <= 4, c[deg] != 0) inside
-// [-bound, bound], ascending.  `crit` = sorted real roots of the derivative.
-__device__ int roots_between(const double *c, int deg, const double *crit, int ncrit, double bound,
-                             double *out) {
+template <int N>
+__device__ __forceinline__ void put(double (&a)[N], int at, double v) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) a[j] = (j == at) ? v : a[j];
+}
+template <int N>
+__device__ __forceinline__ double get(const double (&a)[N], int at) {
+  double v = a[0];
+#pragma unroll
+  for (int j = 1; j < N; ++j) v = (j == at) ? a[j] : v;
+  return v;
+}
+
+// Real roots of c (degree DEG, c[DEG] != 0) inside [-bound, bound], ascending.
+// crit[0..ncrit) = sorted real roots of the derivative (at most DEG-1 of them).
+template <int DEG>
+__device__ __forceinline__ int roots_between(const double (&c)[DEG + 1], const double (&crit)[DEG],
+                                             int ncrit, double bound, double (&out)[DEG]) {
   int n = 0;
-  double lo = -bound, flo = horner(c, deg, lo);
-  for (int k = 0; k <= ncrit; ++k) {
-    const double hi = (k < ncrit) ? fmin(fmax(crit[k], -bound), bound) : bound;
-    const double fhi = horner(c, deg, hi);
-    if (flo == 0.0) {
-      if (n == 0 || out[n - 1] != lo) out[n++] = lo;
-    } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0)) && hi > lo) {
-      out[n++] = bracketed_root(c, deg, lo, hi, flo);
+  double lo = -bound, flo = horner<DEG>(c, lo);
+#pragma unroll
+  for (int k = 0; k < DEG; ++k) {
+    if (k <= ncrit && n < DEG) {
+      const double hi = (k < ncrit) ? fmin(fmax(crit[k], -bound), bound) : bound;
+      const double fhi = horner<DEG>(c, hi);
+      if (flo == 0.0) {
+        if (n == 0 || get<DEG>(out, n - 1) != lo) { put<DEG>(out, n, lo); ++n; }
+      } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0)) && hi > lo) {
+        put<DEG>(out, n, bracketed_root<DEG>(c, lo, hi, flo));
+        ++n;
+      }
+      lo = hi;
+      flo = fhi;
     }
-    lo = hi;
-    flo = fhi;
-    if (n >= deg) break;
   }
-  if (n < deg && flo == 0.0 && (n == 0 || out[n - 1] != lo)) out[n++] = lo;
+  if (n < DEG && flo == 0.0 && (n == 0 || get<DEG>(out, n - 1) != lo)) { put<DEG>(out, n, lo); ++n; }
   return n;
 }
 
-__device__ double cauchy_bound(const double *c, int deg) {
+template <int DEG>
+__device__ __forceinline__ double cauchy_bound(const double (&c)[DEG + 1]) {
   double m = 0.0;
-  for (int i = 0; i < deg; ++i) m = fmax(m, fabs(c[i] / c[deg]));
+#pragma unroll
+  for (int i = 0; i < DEG; ++i) m = fmax(m, fabs(c[i] / c[DEG]));
   return 1.0 + m;
 }
 
-__device__ int quartic_real_roots(const double *q, double *roots) {
+__device__ __forceinline__ int quartic_real_roots(const double (&q)[5], double (&roots)[4]) {
   // q has degree 4 with q[4] != 0
   double c3[4], c2[3];
+#pragma unroll
   for (int i = 1; i <= 4; ++i) c3[i - 1] = q[i] * (double)i;
+#pragma unroll
   for (int i = 1; i <= 3; ++i) c2[i - 1] = c3[i] * (double)i;
-  // quadratic c2 roots
-  double r2[2];
+  // real roots of the quadratic c2 (critical points of the cubic), sorted
+  double r2[3] = {0.0, 0.0, 0.0};
   int n2 = 0;
   {
     const double a = c2[2], b = c2[1], c = c2[0];
@@ -79,9 +108,10 @@ __device__ int quartic_real_roots(const double *q, double *roots) {
       r2[0] = x1; r2[1] = x2; n2 = (x1 == x2) ? 1 : 2;
     }
   }
-  double r3[3];
-  const int n3 = roots_between(c3, 3, r2, n2, cauchy_bound(c3, 3), r3);
-  return roots_between(q, 4, r3, n3, cauchy_bound(q, 4), roots);
+  double r3[3] = {0.0, 0.0, 0.0};
+  const int n3 = roots_between<3>(c3, r2, n2, cauchy_bound<3>(c3), r3);
+  double crit4[4] = {r3[0], r3[1], r3[2], 0.0};
+  return roots_between<4>(q, crit4, n3, cauchy_bound<4>(q), roots);
 }
 
 __device__ __forceinline__ void cross3(const double *a, const double *b, double *o) {
@@ -158,11 +188,13 @@ __device__ __noinline__ bool p3p_lane(const double (&X)[4][3], const double (&f)
       for (int j = 0; j < 4; ++j) quart[i + j] -= q[i] * r[j];
     double scale = 0.0;
     for (int i = 0; i < 5; ++i) scale = fmax(scale, fabs(quart[i]));
-    double vr[4];
+    double vr[4] = {0.0, 0.0, 0.0, 0.0};
     int nroots = 0;
     if (scale > 0.0 && fabs(quart[4]) > 1e-14 * scale) nroots = quartic_real_roots(quart, vr);
 
-    for (int s = 0; s < nroots; ++s) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      if (s >= nroots) continue;
       const double v = vr[s];
       if (!(v > 0.0)) continue;
       const double qv = q[0] + q[1] * v;

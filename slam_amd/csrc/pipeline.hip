@@ -164,6 +164,43 @@ struct RansacParams {
   unsigned long long seed;
 };
 
+// Consensus count of one lane's pose against all n correspondences of the pair
+// (both cameras).  Every lane of the block calls it: the points are staged
+// through LDS chunk by chunk with block barriers.  Kept out of line so that its
+// registers are allocated apart from the minimal solver's.
+__device__ __noinline__ int score_round(bool valid, const double *rt_all, const RansacCam *cam,
+                                        double *lds, const float *__restrict__ X,
+                                        const float *__restrict__ mL,
+                                        const float *__restrict__ mR, int n, double thresh) {
+  double PL[12], PR[12];
+  if (valid) {
+    double Rt[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) Rt[i] = rt_all[i * kBlock + threadIdx.x];
+    make_projections(Rt, *cam, PL, PR);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) PL[i] = PR[i] = 0.0;
+  }
+  const double thr2 = thresh * thresh;
+  int c = 0;
+  for (int p0 = 0; p0 < n; p0 += kPtsPerChunk) {
+    const int cnt = min(kPtsPerChunk, n - p0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += kBlock) {
+      const size_t g = (size_t)(p0 + i);
+      double *o = lds + i * kPtStride;
+      o[0] = (double)X[3 * g]; o[1] = (double)X[3 * g + 1]; o[2] = (double)X[3 * g + 2];
+      o[3] = (double)mL[2 * g]; o[4] = (double)mL[2 * g + 1];
+      o[5] = (double)mR[2 * g]; o[6] = (double)mR[2 * g + 1];
+      o[7] = 0.0;
+    }
+    __syncthreads();
+    if (valid) c += count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
+  }
+  return c;
+}
+
 __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
@@ -172,6 +209,8 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   __shared__ int counts[kBlock];
   __shared__ double best_rt[12];
+  __shared__ double rt_all[12 * kBlock];  // this round's poses, element-major: [i * kBlock + lane]
+  __shared__ RansacCam cam_lds;
   __shared__ int st[8];  // best_count, best_idx, iter_done, n_req, stop, winner_lane, domain, mask_count
   const int p = blockIdx.x;
   const int base = obase[p];
@@ -183,6 +222,8 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
     st[0] = 0; st[1] = -1; st[2] = 0; st[3] = prm.n_iter_max; st[4] = 0; st[5] = -1; st[6] = 0; st[7] = 0;
   }
   if (threadIdx.x < 12) best_rt[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;  // [I|0]
+  if (threadIdx.x < 9) cam_lds.K[threadIdx.x] = prm.cam.K[threadIdx.x];
+  if (threadIdx.x < 12) cam_lds.MR[threadIdx.x] = prm.cam.MR[threadIdx.x];
   __syncthreads();
   const double thr2 = prm.thresh * prm.thresh;
   const double log1mp = log(1.0 - prm.p_success);
@@ -191,9 +232,9 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
     for (int round = 0;; ++round) {
       const int it = round * kBlock + (int)threadIdx.x;
       const bool active = it < prm.n_iter_max;
-      double Rt[12];
       bool valid = false;
       if (active) {
+        double Rt[12];
         int s4[4];
         if (samples != nullptr) {
           const int32_t *sp = samples + ((size_t)p * prm.n_iter_max + it) * 4;
@@ -221,31 +262,10 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
           if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
         }
         valid = p3p_lane(Xs, f, nrm4, Rt);
+        if (valid)
+          for (int i = 0; i < 12; ++i) rt_all[i * kBlock + threadIdx.x] = Rt[i];
       }
-      double PL[12], PR[12];
-      if (valid) make_projections(Rt, prm.cam, PL, PR);
-      int c = 0;
-      for (int p0 = 0; p0 < n; p0 += kPtsPerChunk) {
-        const int cnt = min(kPtsPerChunk, n - p0);
-        __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += kBlock) {
-          const size_t g = (size_t)(p0 + i);
-          double *o = lds + i * kPtStride;
-          o[0] = (double)X[3 * g]; o[1] = (double)X[3 * g + 1]; o[2] = (double)X[3 * g + 2];
-          o[3] = (double)mL[2 * g]; o[4] = (double)mL[2 * g + 1];
-          o[5] = (double)mR[2 * g]; o[6] = (double)mR[2 * g + 1];
-          o[7] = 0.0;
-        }
-        __syncthreads();
-        if (valid) {
-          for (int i = 0; i < cnt; ++i) {
-            const double *q = lds + i * kPtStride;
-            const bool inL = inlier_one_camera(PL, q[0], q[1], q[2], q[3], q[4], prm.thresh, thr2);
-            const bool inR = inlier_one_camera(PR, q[0], q[1], q[2], q[5], q[6], prm.thresh, thr2);
-            c += (inL && inR) ? 1 : 0;
-          }
-        }
-      }
+      const int c = score_round(valid, rt_all, &cam_lds, lds, X, mL, mR, n, prm.thresh);
       counts[threadIdx.x] = active ? (valid ? c : -1) : -2;
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -273,8 +293,7 @@ __global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
         st[4] = (iter_done < n_req && iter_done < prm.n_iter_max) ? 0 : 1;
       }
       __syncthreads();
-      if ((int)threadIdx.x == st[5])
-        for (int i = 0; i < 12; ++i) best_rt[i] = Rt[i];
+      if (threadIdx.x < 12 && st[5] >= 0) best_rt[threadIdx.x] = rt_all[threadIdx.x * kBlock + st[5]];
       __syncthreads();
       if (st[4]) break;
     }

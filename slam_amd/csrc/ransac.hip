@@ -65,14 +65,7 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(
   double PL[12], PR[12];
   make_projections(Rt + 12 * (size_t)hyp, cam, PL, PR);
   const double thr2 = thr * thr;
-  int c = 0;
-  for (int i = 0; i < cnt; ++i) {
-    const double *q = lds + i * kPtStride;
-    const double X = q[0], Y = q[1], Z = q[2];
-    const bool inL = inlier_one_camera(PL, X, Y, Z, q[3], q[4], thr, thr2);
-    const bool inR = inlier_one_camera(PR, X, Y, Z, q[5], q[6], thr, thr2);
-    c += (inL && inR) ? 1 : 0;
-  }
+  const int c = count_chunk_inliers(lds, cnt, PL, PR, thr, thr2);
   if (gridDim.y == 1) counts[hyp] = c;
   else if (c != 0) atomicAdd(&counts[hyp], c);
 }

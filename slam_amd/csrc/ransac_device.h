@@ -46,7 +46,7 @@ __device__ __forceinline__ void make_projections(const double *__restrict__ Rt,
 }
 
 // Literal reference sequence for one camera (used for borderline points only).
-__device__ __noinline__ bool inlier_exact(double x, double y, double w, double mu, double mv,
+__device__ __forceinline__ bool inlier_exact(double x, double y, double w, double mu, double mv,
                                           double thr) {
   const double u = x / w, v = y / w;
   const double dx = __dsub_rn(mu, u), dy = __dsub_rn(mv, v);
@@ -67,6 +67,21 @@ __device__ __forceinline__ bool inlier_one_camera(const double (&P)[12], double 
   bool in = lhs <= rhs;
   if (!(fabs(lhs - rhs) > 1e-10 * rhs)) in = inlier_exact(x, y, w, mu, mv, thr);
   return in;
+}
+
+// Inliers (both cameras) among `cnt` points staged in LDS as kPtStride doubles
+// each (X, Y, Z, uL, vL, uR, vR, pad).
+__device__ __forceinline__ int count_chunk_inliers(const double *__restrict__ lds, int cnt,
+                                                   const double (&PL)[12], const double (&PR)[12],
+                                                   double thr, double thr2) {
+  int c = 0;
+  for (int i = 0; i < cnt; ++i) {
+    const double *q = lds + i * kPtStride;
+    const bool inL = inlier_one_camera(PL, q[0], q[1], q[2], q[3], q[4], thr, thr2);
+    const bool inR = inlier_one_camera(PR, q[0], q[1], q[2], q[5], q[6], thr, thr2);
+    c += (inL && inR) ? 1 : 0;
+  }
+  return c;
 }
 
 }  // namespace slamhip_dev
