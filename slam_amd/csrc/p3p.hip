@@ -12,8 +12,9 @@
 //   d_i^2 + d_j^2 - 2 d_i d_j (f_i.f_j) = |X_i - X_j|^2 for the three pairs.
 //   With d2 = u d1, d3 = v d1 two quadratics in (u, v) remain; their resultant
 //   in u is a quartic in v whose coefficients are formed numerically by
-//   polynomial products.  Real roots are bracketed between the critical points
-//   (quadratic -> cubic -> quartic) and polished by safeguarded Newton steps;
+//   polynomial products.  Its real roots come from the closed-form
+//   factorisation through the resolvent cubic, polished by guarded Newton
+//   steps on the quartic itself (quartic.h; straight-line code, no divergence);
 //   u follows from the common-root relation; depths are polished by two
 //   Gauss-Newton steps on the three distance equations; the pose is the rigid
 //   alignment of the two triangles.

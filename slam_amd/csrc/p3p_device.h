@@ -2,117 +2,11 @@
 // problem per lane, fp64.  Method: see p3p.hip.
 #pragma once
 #include <hip/hip_runtime.h>
+#include "quartic.h"
 
 namespace slamhip_dev {
 
 struct Kinv { double m[9]; };
-
-// Polynomials are fixed-size register arrays (c[0] + c[1] x + ... + c[DEG] x^DEG)
-// and every loop over them is fully unrolled, so nothing here is indexed at
-// run time and nothing goes to scratch memory.
-template <int DEG>
-__device__ __forceinline__ double horner(const double (&c)[DEG + 1], double x) {
-  double r = c[DEG];
-#pragma unroll
-  for (int i = DEG - 1; i >= 0; --i) r = fma(r, x, c[i]);
-  return r;
-}
-
-// Root of c inside [lo, hi] given a sign change; bisection with Newton
-// acceleration, always kept inside the bracket.
-template <int DEG>
-__device__ __forceinline__ double bracketed_root(const double (&c)[DEG + 1], double lo, double hi,
-                                                 double flo) {
-  double d[DEG];
-#pragma unroll
-  for (int i = 1; i <= DEG; ++i) d[i - 1] = c[i] * (double)i;
-  double x = 0.5 * (lo + hi);
-  for (int it = 0; it < 64; ++it) {
-    const double fx = horner<DEG>(c, x);
-    if (fx == 0.0) return x;
-    if ((fx < 0.0) == (flo < 0.0)) lo = x; else hi = x;
-    const double dfx = horner<DEG - 1>(d, x);
-    double xn = x - fx / dfx;
-    if (!(xn > lo && xn < hi)) xn = 0.5 * (lo + hi);
-    if (fabs(xn - x) <= 4.4e-16 * fmax(1.0, fabs(xn))) return xn;
-    x = xn;
-  }
-  return x;
-}
-
-template <int N>
-__device__ __forceinline__ void put(double (&a)[N], int at, double v) {
-#pragma unroll
-  for (int j = 0; j < N; ++j) a[j] = (j == at) ? v : a[j];
-}
-template <int N>
-__device__ __forceinline__ double get(const double (&a)[N], int at) {
-  double v = a[0];
-#pragma unroll
-  for (int j = 1; j < N; ++j) v = (j == at) ? a[j] : v;
-  return v;
-}
-
-// Real roots of c (degree DEG, c[DEG] != 0) inside [-bound, bound], ascending.
-// crit[0..ncrit) = sorted real roots of the derivative (at most DEG-1 of them).
-template <int DEG>
-__device__ __forceinline__ int roots_between(const double (&c)[DEG + 1], const double (&crit)[DEG],
-                                             int ncrit, double bound, double (&out)[DEG]) {
-  int n = 0;
-  double lo = -bound, flo = horner<DEG>(c, lo);
-#pragma unroll
-  for (int k = 0; k < DEG; ++k) {
-    if (k <= ncrit && n < DEG) {
-      const double hi = (k < ncrit) ? fmin(fmax(crit[k], -bound), bound) : bound;
-      const double fhi = horner<DEG>(c, hi);
-      if (flo == 0.0) {
-        if (n == 0 || get<DEG>(out, n - 1) != lo) { put<DEG>(out, n, lo); ++n; }
-      } else if (fhi != 0.0 && ((flo < 0.0) != (fhi < 0.0)) && hi > lo) {
-        put<DEG>(out, n, bracketed_root<DEG>(c, lo, hi, flo));
-        ++n;
-      }
-      lo = hi;
-      flo = fhi;
-    }
-  }
-  if (n < DEG && flo == 0.0 && (n == 0 || get<DEG>(out, n - 1) != lo)) { put<DEG>(out, n, lo); ++n; }
-  return n;
-}
-
-template <int DEG>
-__device__ __forceinline__ double cauchy_bound(const double (&c)[DEG + 1]) {
-  double m = 0.0;
-#pragma unroll
-  for (int i = 0; i < DEG; ++i) m = fmax(m, fabs(c[i] / c[DEG]));
-  return 1.0 + m;
-}
-
-__device__ __forceinline__ int quartic_real_roots(const double (&q)[5], double (&roots)[4]) {
-  // q has degree 4 with q[4] != 0
-  double c3[4], c2[3];
-#pragma unroll
-  for (int i = 1; i <= 4; ++i) c3[i - 1] = q[i] * (double)i;
-#pragma unroll
-  for (int i = 1; i <= 3; ++i) c2[i - 1] = c3[i] * (double)i;
-  // real roots of the quadratic c2 (critical points of the cubic), sorted
-  double r2[3] = {0.0, 0.0, 0.0};
-  int n2 = 0;
-  {
-    const double a = c2[2], b = c2[1], c = c2[0];
-    const double disc = b * b - 4.0 * a * c;
-    if (disc >= 0.0) {
-      const double s = sqrt(disc);
-      const double qq = -0.5 * (b + copysign(s, b));
-      double x1 = qq / a, x2 = (qq != 0.0) ? c / qq : x1;
-      if (x1 > x2) { const double t = x1; x1 = x2; x2 = t; }
-      r2[0] = x1; r2[1] = x2; n2 = (x1 == x2) ? 1 : 2;
-    }
-  }
-  double r3[3] = {0.0, 0.0, 0.0};
-  const int n3 = roots_between<3>(c3, r2, n2, cauchy_bound<3>(c3), r3);
-  double crit4[4] = {r3[0], r3[1], r3[2], 0.0};
-  return roots_between<4>(q, crit4, n3, cauchy_bound<4>(q), roots);
-}
 
 __device__ __forceinline__ void cross3(const double *a, const double *b, double *o) {
   o[0] = a[1] * b[2] - a[2] * b[1];
@@ -190,7 +84,7 @@ __device__ __noinline__ bool p3p_lane(const double (&X)[4][3], const double (&f)
     for (int i = 0; i < 5; ++i) scale = fmax(scale, fabs(quart[i]));
     double vr[4] = {0.0, 0.0, 0.0, 0.0};
     int nroots = 0;
-    if (scale > 0.0 && fabs(quart[4]) > 1e-14 * scale) nroots = quartic_real_roots(quart, vr);
+    if (scale > 0.0 && fabs(quart[4]) > 1e-14 * scale) nroots = quartic_real_roots_closed(quart, vr);
 
 #pragma unroll
     for (int s = 0; s < 4; ++s) {

@@ -142,17 +142,57 @@ __global__ __launch_bounds__(kBlock) void temporal_gather_kernel(
   }
 }
 
-// --------------------------------------------------------------------------
-// Adaptive RANSAC, one workgroup per pair.  256 hypotheses are sampled, solved
-// (P3P) and scored against every point per round; lane 0 then replays the
-// sequential stopping rule of pnp.py:123-158 over the round's ordered counts,
-// so the outcome equals the one-hypothesis-at-a-time loop on the same samples.
-// --------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
   x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
   return x ^ (x >> 31);
+}
+
+// Adaptive RANSAC over many pairs, run as rounds of kHypPerRound hypotheses
+// per pair.  A round is two launches over all pairs that are still running:
+// "solve" (sample + P3P, one lane per hypothesis) and "count" (every
+// hypothesis against every correspondence, both cameras, partial counts added
+// atomically).  The next solve launch (or the finishing launch) first replays
+// the sequential stopping rule of pnp.py:123-158 over the round's counts in
+// hypothesis order, so the outcome equals the one-hypothesis-at-a-time loop on
+// the same samples; a pair that has stopped costs later launches one load.
+// Splitting the rounds into launches keeps every CU busy however unevenly the
+// pairs' iteration counts fall: a pair that needs ten rounds does not hold a
+// CU while the rest of the chip has nothing left to do.
+//
+// Per-pair state is the caller's 8-int info record: best_idx, best_count,
+// iterations done, iterations required, domain-error flag, n, mask count,
+// stopped flag (cleared again by the finishing launch).
+constexpr int kHypPerRound = kBlock;
+constexpr int kPairGroup = 4096;   // pairs per group of launches (bounds the pose table)
+
+// Replays hypotheses [round*kHypPerRound, ...) of one pair; returns the lane of
+// a new best hypothesis of this round or -1.
+__device__ int replay_round(int32_t *__restrict__ s, const int32_t *__restrict__ counts, int round,
+                            int n, int n_iter_max, double log1mp) {
+  int best_idx = s[0], best_count = s[1], iter_done = s[2], n_req = s[3];
+  int winner = -1;
+  while (iter_done < n_req && iter_done < n_iter_max && iter_done < (round + 1) * kHypPerRound) {
+    const int cc = counts[iter_done - round * kHypPerRound];
+    const int idx = iter_done;
+    ++iter_done;
+    if (cc < 0) continue;            // no pose from this sample: the reference skips it
+    if (cc > best_count) {
+      best_count = cc;
+      best_idx = idx;
+      winner = idx - round * kHypPerRound;
+      const double w = (double)best_count / (double)n;
+      const double w2 = w * w;
+      const double den = log(1.0 - w2 * w2);
+      if (best_count >= n) s[4] = 1;  // log(0): the reference raises here
+      const double r = ceil(log1mp / den);
+      n_req = r > 2147483647.0 ? 2147483647 : (int)r;
+    }
+  }
+  s[0] = best_idx; s[1] = best_count; s[2] = iter_done; s[3] = n_req;
+  s[7] = (iter_done < n_req && iter_done < n_iter_max) ? 0 : 1;
+  return winner;
 }
 
 struct RansacParams {
@@ -162,174 +202,231 @@ struct RansacParams {
   int n_iter_max;
   int min_points;  // pairs with fewer correspondences are not attempted
   unsigned long long seed;
+  long long pair0;  // index of the launch's first pair in the caller's numbering (sampling)
 };
 
-// Consensus count of one lane's pose against all n correspondences of the pair
-// (both cameras).  Every lane of the block calls it: the points are staged
-// through LDS chunk by chunk with block barriers.  Kept out of line so that its
-// registers are allocated apart from the minimal solver's.
-__device__ __noinline__ int score_round(bool valid, const double *rt_all, const RansacCam *cam,
-                                        double *lds, const float *__restrict__ X,
-                                        const float *__restrict__ mL,
-                                        const float *__restrict__ mR, int n, double thresh) {
+// Pose table layout: rt[(pair * 12 + element) * kHypPerRound + lane].
+__global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
+    int round, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    const float *__restrict__ cx, const float *__restrict__ cpl,
+    const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
+    int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info) {
+  __shared__ int sh[2];  // stopped, winner lane of the replayed round
+  const int p = blockIdx.x;
+  int32_t *s = info + 8 * (size_t)p;
+  const int n = tm_count[p];
+  if (threadIdx.x == 0) {
+    int winner = -1;
+    if (round == 0) {
+      s[0] = -1; s[1] = 0; s[2] = 0; s[3] = prm.n_iter_max; s[4] = 0; s[5] = n; s[6] = 0;
+      s[7] = (n >= 4 && n >= prm.min_points) ? 0 : 1;
+    } else if (!s[7]) {
+      winner = replay_round(s, counts + (size_t)p * kHypPerRound, round - 1, n, prm.n_iter_max,
+                            log(1.0 - prm.p_success));
+    }
+    sh[0] = s[7];
+    sh[1] = winner;
+  }
+  __syncthreads();
+  if (threadIdx.x < 12) {
+    if (round == 0)
+      pose_ransac[12 * (size_t)p + threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;  // [I|0]
+    else if (sh[1] >= 0)
+      pose_ransac[12 * (size_t)p + threadIdx.x] =
+          rt[((size_t)p * 12 + threadIdx.x) * kHypPerRound + sh[1]];
+  }
+  if (sh[0]) return;
+  __syncthreads();  // the winner has been read before its slot is overwritten
+
+  const int it = round * kHypPerRound + (int)threadIdx.x;
+  const bool active = it < prm.n_iter_max;
+  bool valid = false;
+  if (active) {
+    const float *X = cx + 3 * (size_t)obase[p];
+    const float *mL = cpl + 2 * (size_t)obase[p];
+    const unsigned long long gp = (unsigned long long)(prm.pair0 + p);
+    int s4[4];
+    if (samples != nullptr) {
+      const int32_t *sp = samples + ((size_t)gp * prm.n_iter_max + it) * 4;
+      for (int k = 0; k < 4; ++k) s4[k] = min(max(sp[k], 0), n - 1);
+    } else {
+      unsigned long long r = splitmix64(prm.seed ^ (gp << 32) ^ (unsigned long long)it);
+      for (int k = 0; k < 4; ++k) {
+        int c = 0;
+        for (int tries = 0; tries < 64; ++tries) {
+          r = splitmix64(r);
+          c = (int)(((r >> 32) * (unsigned long long)n) >> 32);
+          bool dup = false;
+          for (int j = 0; j < k; ++j) dup |= (s4[j] == c);
+          if (!dup) break;
+        }
+        s4[k] = c;
+      }
+    }
+    double Xs[4][3], f[4][3], nrm4[2], Rt[12];
+    for (int k = 0; k < 4; ++k) {
+      for (int c = 0; c < 3; ++c) Xs[k][c] = (double)X[3 * (size_t)s4[k] + c];
+      double nk[2];
+      pixel_to_bearing(prm.kinv, (double)mL[2 * (size_t)s4[k]], (double)mL[2 * (size_t)s4[k] + 1],
+                       f[k], nk);
+      if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
+    }
+    valid = p3p_lane(Xs, f, nrm4, Rt);
+    if (valid)
+      for (int i = 0; i < 12; ++i) rt[((size_t)p * 12 + i) * kHypPerRound + threadIdx.x] = Rt[i];
+  }
+  counts[(size_t)p * kHypPerRound + threadIdx.x] = active ? (valid ? 0 : -1) : -2;
+}
+
+// grid (point spans, kHypPerRound / 64, pairs), one wavefront per block; a span is
+// `chunks_per_span` LDS-staged chunks of kPtsPerChunk correspondences.  The first
+// rounds, which most pairs need, use one chunk per block for parallelism; later
+// rounds, which few pairs reach, use one block per 64 hypotheses so that a launch
+// with nothing left to do costs a few thousand empty blocks instead of tens of
+// thousands.
+constexpr int kWideRounds = 3;
+__global__ __launch_bounds__(64) void ransac_count_kernel(
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
+    RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
+    const int32_t *__restrict__ info, int chunks_per_span) {
+  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
+  const int p = blockIdx.z;
+  if (info[8 * (size_t)p + 7]) return;
+  const int n = tm_count[p];
+  const int span0 = blockIdx.x * (chunks_per_span * kPtsPerChunk);
+  if (span0 >= n) return;
+  const int span1 = min(n, span0 + chunks_per_span * kPtsPerChunk);
+  const int hyp = blockIdx.y * 64 + (int)threadIdx.x;
+  int32_t *slot = counts + (size_t)p * kHypPerRound + hyp;
+  // a valid hypothesis' slot starts at 0 and only grows; invalid ones hold -1 / -2
+  const bool valid = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+  if (!__any(valid)) return;
   double PL[12], PR[12];
-  if (valid) {
+  {
     double Rt[12];
 #pragma unroll
-    for (int i = 0; i < 12; ++i) Rt[i] = rt_all[i * kBlock + threadIdx.x];
-    make_projections(Rt, *cam, PL, PR);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 12; ++i) PL[i] = PR[i] = 0.0;
+    for (int i = 0; i < 12; ++i)
+      Rt[i] = valid ? rt[((size_t)p * 12 + i) * kHypPerRound + hyp] : 0.0;
+    make_projections(Rt, cam, PL, PR);
   }
   const double thr2 = thresh * thresh;
   int c = 0;
-  for (int p0 = 0; p0 < n; p0 += kPtsPerChunk) {
-    const int cnt = min(kPtsPerChunk, n - p0);
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += kBlock) {
-      const size_t g = (size_t)(p0 + i);
+  for (int p0 = span0; p0 < span1; p0 += kPtsPerChunk) {
+    const size_t base = (size_t)obase[p] + p0;
+    const int cnt = min(kPtsPerChunk, span1 - p0);
+    if (p0 != span0) __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 64) {
+      const size_t g = base + i;
       double *o = lds + i * kPtStride;
-      o[0] = (double)X[3 * g]; o[1] = (double)X[3 * g + 1]; o[2] = (double)X[3 * g + 2];
-      o[3] = (double)mL[2 * g]; o[4] = (double)mL[2 * g + 1];
-      o[5] = (double)mR[2 * g]; o[6] = (double)mR[2 * g + 1];
+      o[0] = (double)cx[3 * g]; o[1] = (double)cx[3 * g + 1]; o[2] = (double)cx[3 * g + 2];
+      o[3] = (double)cpl[2 * g]; o[4] = (double)cpl[2 * g + 1];
+      o[5] = (double)cpr[2 * g]; o[6] = (double)cpr[2 * g + 1];
       o[7] = 0.0;
     }
     __syncthreads();
     if (valid) c += count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
   }
-  return c;
+  if (valid && c) atomicAdd(slot, c);
 }
 
-__global__ __launch_bounds__(kBlock) void ransac_pairs_kernel(
-    const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+// Replays the last round, then writes the winner's mask, its count and the
+// final info record.
+__global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
+    int rounds, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
-    const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ pose_ransac,
-    uint8_t *__restrict__ tm_mask, int32_t *__restrict__ info) {
-  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
-  __shared__ int counts[kBlock];
+    RansacParams prm, const double *__restrict__ rt, const int32_t *__restrict__ counts,
+    double *__restrict__ pose_ransac, uint8_t *__restrict__ tm_mask, int32_t *__restrict__ info) {
+  __shared__ int sh[3];  // winner lane, have a best hypothesis, mask count
   __shared__ double best_rt[12];
-  __shared__ double rt_all[12 * kBlock];  // this round's poses, element-major: [i * kBlock + lane]
-  __shared__ RansacCam cam_lds;
-  __shared__ int st[8];  // best_count, best_idx, iter_done, n_req, stop, winner_lane, domain, mask_count
   const int p = blockIdx.x;
-  const int base = obase[p];
+  int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
-  const float *X = cx + 3 * (size_t)base;
-  const float *mL = cpl + 2 * (size_t)base;
-  const float *mR = cpr + 2 * (size_t)base;
   if (threadIdx.x == 0) {
-    st[0] = 0; st[1] = -1; st[2] = 0; st[3] = prm.n_iter_max; st[4] = 0; st[5] = -1; st[6] = 0; st[7] = 0;
+    int winner = -1;
+    if (!s[7])
+      winner = replay_round(s, counts + (size_t)p * kHypPerRound, rounds - 1, n, prm.n_iter_max,
+                            log(1.0 - prm.p_success));
+    sh[0] = winner;
+    sh[1] = s[0] >= 0;
+    sh[2] = 0;
   }
-  if (threadIdx.x < 12) best_rt[threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;  // [I|0]
-  if (threadIdx.x < 9) cam_lds.K[threadIdx.x] = prm.cam.K[threadIdx.x];
-  if (threadIdx.x < 12) cam_lds.MR[threadIdx.x] = prm.cam.MR[threadIdx.x];
   __syncthreads();
+  if (threadIdx.x < 12) {
+    const double v = sh[0] >= 0 ? rt[((size_t)p * 12 + threadIdx.x) * kHypPerRound + sh[0]]
+                                : pose_ransac[12 * (size_t)p + threadIdx.x];
+    best_rt[threadIdx.x] = v;
+    pose_ransac[12 * (size_t)p + threadIdx.x] = v;
+  }
+  __syncthreads();
+  const size_t base = (size_t)obase[p];
+  const float *X = cx + 3 * base, *mL = cpl + 2 * base, *mR = cpr + 2 * base;
+  double Rt[12], PL[12], PR[12];
+  for (int i = 0; i < 12; ++i) Rt[i] = best_rt[i];
+  make_projections(Rt, prm.cam, PL, PR);
   const double thr2 = prm.thresh * prm.thresh;
-  const double log1mp = log(1.0 - prm.p_success);
-
-  if (n >= 4 && n >= prm.min_points) {
-    for (int round = 0;; ++round) {
-      const int it = round * kBlock + (int)threadIdx.x;
-      const bool active = it < prm.n_iter_max;
-      bool valid = false;
-      if (active) {
-        double Rt[12];
-        int s4[4];
-        if (samples != nullptr) {
-          const int32_t *sp = samples + ((size_t)p * prm.n_iter_max + it) * 4;
-          for (int k = 0; k < 4; ++k) s4[k] = min(max(sp[k], 0), n - 1);
-        } else {
-          unsigned long long s = splitmix64(prm.seed ^ ((unsigned long long)p << 32) ^ (unsigned long long)it);
-          for (int k = 0; k < 4; ++k) {
-            int c = 0;
-            for (int tries = 0; tries < 64; ++tries) {
-              s = splitmix64(s);
-              c = (int)(((s >> 32) * (unsigned long long)n) >> 32);
-              bool dup = false;
-              for (int j = 0; j < k; ++j) dup |= (s4[j] == c);
-              if (!dup) break;
-            }
-            s4[k] = c;
-          }
-        }
-        double Xs[4][3], f[4][3], nrm4[2];
-        for (int k = 0; k < 4; ++k) {
-          for (int c = 0; c < 3; ++c) Xs[k][c] = (double)X[3 * (size_t)s4[k] + c];
-          double nk[2];
-          pixel_to_bearing(prm.kinv, (double)mL[2 * (size_t)s4[k]], (double)mL[2 * (size_t)s4[k] + 1],
-                           f[k], nk);
-          if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
-        }
-        valid = p3p_lane(Xs, f, nrm4, Rt);
-        if (valid)
-          for (int i = 0; i < 12; ++i) rt_all[i * kBlock + threadIdx.x] = Rt[i];
-      }
-      const int c = score_round(valid, rt_all, &cam_lds, lds, X, mL, mR, n, prm.thresh);
-      counts[threadIdx.x] = active ? (valid ? c : -1) : -2;
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        int best_count = st[0], best_idx = st[1], iter_done = st[2], n_req = st[3];
-        int winner = -1;
-        while (iter_done < n_req && iter_done < prm.n_iter_max && iter_done < (round + 1) * kBlock) {
-          const int cc = counts[iter_done - round * kBlock];
-          const int idx = iter_done;
-          ++iter_done;
-          if (cc < 0) continue;
-          if (cc > best_count) {
-            best_count = cc;
-            best_idx = idx;
-            winner = idx - round * kBlock;
-            const double w = (double)best_count / (double)n;
-            const double w2 = w * w;
-            const double den = log(1.0 - w2 * w2);
-            if (best_count >= n) st[6] = 1;
-            const double r = ceil(log1mp / den);
-            n_req = r > 2147483647.0 ? 2147483647 : (int)r;
-          }
-        }
-        st[0] = best_count; st[1] = best_idx; st[2] = iter_done; st[3] = n_req;
-        st[5] = winner;
-        st[4] = (iter_done < n_req && iter_done < prm.n_iter_max) ? 0 : 1;
-      }
-      __syncthreads();
-      if (threadIdx.x < 12 && st[5] >= 0) best_rt[threadIdx.x] = rt_all[threadIdx.x * kBlock + st[5]];
-      __syncthreads();
-      if (st[4]) break;
+  const bool have = sh[1] != 0;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    bool in = false;
+    if (have) {
+      const double Xd = (double)X[3 * (size_t)i], Yd = (double)X[3 * (size_t)i + 1],
+                   Zd = (double)X[3 * (size_t)i + 2];
+      in = inlier_one_camera(PL, Xd, Yd, Zd, (double)mL[2 * (size_t)i], (double)mL[2 * (size_t)i + 1],
+                             prm.thresh, thr2) &&
+           inlier_one_camera(PR, Xd, Yd, Zd, (double)mR[2 * (size_t)i], (double)mR[2 * (size_t)i + 1],
+                             prm.thresh, thr2);
     }
-  }
-
-  // winner's mask and its count
-  {
-    double Rt[12], PL[12], PR[12];
-    for (int i = 0; i < 12; ++i) Rt[i] = best_rt[i];
-    make_projections(Rt, prm.cam, PL, PR);
-    const bool have = st[1] >= 0;
-    for (int i = threadIdx.x; i < n; i += kBlock) {
-      bool in = false;
-      if (have) {
-        const double Xd = (double)X[3 * (size_t)i], Yd = (double)X[3 * (size_t)i + 1],
-                     Zd = (double)X[3 * (size_t)i + 2];
-        in = inlier_one_camera(PL, Xd, Yd, Zd, (double)mL[2 * (size_t)i], (double)mL[2 * (size_t)i + 1],
-                               prm.thresh, thr2) &&
-             inlier_one_camera(PR, Xd, Yd, Zd, (double)mR[2 * (size_t)i], (double)mR[2 * (size_t)i + 1],
-                               prm.thresh, thr2);
-      }
-      tm_mask[base + i] = in ? 1 : 0;
-      if (in) atomicAdd(&st[7], 1);
-    }
+    tm_mask[base + i] = in ? 1 : 0;
+    if (in) atomicAdd(&sh[2], 1);
   }
   __syncthreads();
-  if (threadIdx.x < 12) pose_ransac[12 * (size_t)p + threadIdx.x] = best_rt[threadIdx.x];
-  if (threadIdx.x == 0) {
-    int32_t *o = info + 8 * (size_t)p;
-    o[0] = st[1]; o[1] = st[0]; o[2] = st[2]; o[3] = st[3]; o[4] = st[6]; o[5] = n; o[6] = st[7]; o[7] = 0;
+  if (threadIdx.x == 0) { s[5] = n; s[6] = sh[2]; s[7] = 0; }
+}
+
+size_t ransac_workspace_bytes(int n_pairs) {
+  const size_t g = (size_t)(n_pairs < kPairGroup ? (n_pairs > 0 ? n_pairs : 1) : kPairGroup);
+  return slamhip_align_up(g * 12 * kHypPerRound * sizeof(double), 256) +
+         slamhip_align_up(g * kHypPerRound * sizeof(int32_t), 256);
+}
+
+// RANSAC for pairs [0, n_pairs) described by obase / tm_count; `prm.pair0` is
+// the first pair's index for sampling.  max_points bounds tm_count.
+int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *cx, const float *cpl,
+                    const float *cpr, const int32_t *samples, RansacParams prm, int n_pairs,
+                    int max_points, double *pose_ransac, uint8_t *tm_mask, int32_t *info, void *ws,
+                    hipStream_t st) {
+  if (n_pairs <= 0) return SLAMHIP_OK;
+  const int group = n_pairs < kPairGroup ? n_pairs : kPairGroup;
+  double *rt = (double *)ws;
+  int32_t *counts =
+      (int32_t *)((uintptr_t)ws + slamhip_align_up((size_t)group * 12 * kHypPerRound * sizeof(double), 256));
+  const int rounds = slamhip_ceil_div(prm.n_iter_max, kHypPerRound);
+  const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
+  const long long pair0 = prm.pair0;
+  for (int g0 = 0; g0 < n_pairs; g0 += group) {
+    const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
+    prm.pair0 = pair0 + g0;
+    for (int r = 0; r < rounds; ++r) {
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np), dim3(kBlock), 0, st, r, obase + g0,
+                         tm_count + g0, cx, cpl, samples, prm, rt, counts,
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0);
+      const int per_span = r < kWideRounds ? 1 : chunks;
+      hipLaunchKernelGGL(ransac_count_kernel,
+                         dim3(slamhip_ceil_div(chunks, per_span), kHypPerRound / 64, np), dim3(64), 0,
+                         st, obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,
+                         info + 8 * (size_t)g0, per_span);
+    }
+    hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds, obase + g0,
+                       tm_count + g0, cx, cpl, cpr, prm, rt, counts, pose_ransac + 12 * (size_t)g0,
+                       tm_mask, info + 8 * (size_t)g0);
+    SLAMHIP_CHECK_LAUNCH();
   }
+  return SLAMHIP_OK;
 }
 
 struct Layout {
   int W;
-  size_t idx2, dist2, order, packL, packR, knn, tidx2, tdist2, order2, cx, cpl, cpr, tcount, total;
+  size_t idx2, dist2, order, packL, packR, knn, tidx2, tdist2, order2, cx, cpl, cpr, tcount, ransac, total;
   size_t knn_bytes;
 };
 
@@ -352,6 +449,7 @@ Layout make_layout(const slamhip_frontend_args *a) {
   L.tidx2 = take(NL * 8); L.tdist2 = take(NL * 8); L.order2 = take(NL * 4);
   L.cx = take(NL * 12); L.cpl = take(NL * 8); L.cpr = take(NL * 8);
   L.tcount = take((size_t)F * 4);
+  L.ransac = take(ransac_workspace_bytes(F - 1));
   L.total = o + 256;
   return L;
 }
@@ -466,9 +564,10 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   prm.n_iter_max = a->n_iter_max;
   prm.min_points = 4;
   prm.seed = a->seed;
-  hipLaunchKernelGGL(ransac_pairs_kernel, dim3(F - 1), dim3(kBlock), 0, st, a->d_off_left, tcount, cx,
-                     cpl, cpr, a->d_samples, prm, a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info);
-  SLAMHIP_CHECK_LAUNCH();
+  prm.pair0 = 0;
+  rc = run_pair_ransac(a->d_off_left, tcount, cx, cpl, cpr, a->d_samples, prm, F - 1, a->max_left,
+                       a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st);
+  if (rc) return rc;
 
   rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, a->d_off_left, tcount, F - 1, a->K,
                                      a->d_pose_ransac, a->refine_iters, a->d_pose_refined, nullptr, st);
@@ -495,6 +594,7 @@ size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
   take(slamhip_internal::knn2_workspace_bytes(a->n_rows_total, a->n_rows_total, chunk, a->max_q,
                                               a->max_t, a->desc_bytes, (long long)a->n_out_total,
                                               true));
+  take(ransac_workspace_bytes(chunk));
   return o + 256;
 }
 
@@ -526,6 +626,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
       a->n_rows_total, a->n_rows_total, chunk_max, a->max_q, a->max_t, a->desc_bytes,
       (long long)a->n_out_total, true);
   void *knn_ws = (void *)take(knn_bytes);
+  void *ransac_ws = (void *)take(ransac_workspace_bytes(chunk_max));
 
   // per keyframe: points of all stored features (loop_closure.py:179-180,237-249: fp64
   // triangulation, later cast to float32 at :209) and packed descriptors
@@ -568,10 +669,11 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
                        a->d_tm_train, a->d_tm_dist, tcount + c0, cx, cpl, cpr);
     SLAMHIP_CHECK_LAUNCH();
     prm.seed = a->seed + (unsigned long long)c0 * 0x9E3779B97F4A7C15ull;
-    hipLaunchKernelGGL(ransac_pairs_kernel, dim3(np), dim3(kBlock), 0, st, ob, tcount + c0, cx, cpl,
-                       cpr, (const int32_t *)nullptr, prm, a->d_pose_ransac + 12 * (size_t)c0,
-                       a->d_tm_mask, a->d_info + 8 * (size_t)c0);
-    SLAMHIP_CHECK_LAUNCH();
+    prm.pair0 = 0;
+    rc = run_pair_ransac(ob, tcount + c0, cx, cpl, cpr, nullptr, prm, np, a->max_q,
+                         a->d_pose_ransac + 12 * (size_t)c0, a->d_tm_mask,
+                         a->d_info + 8 * (size_t)c0, ransac_ws, st);
+    if (rc) return rc;
     rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, ob, tcount + c0, np, a->K,
                                        a->d_pose_ransac + 12 * (size_t)c0, a->refine_iters,
                                        a->d_pose_refined + 12 * (size_t)c0, nullptr, st);
