@@ -150,10 +150,74 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
         "pose_error_vs_truth_max_m": float(max(
             np.abs(res.pair(p)["Rt"][:, 3] - seq.relative_pose(p + 1)[:, 3]).max() for p in range(0, F - 1, 25))),
     }
+    # The same pass with the host on both sides: features start in host memory
+    # (concatenate + H2D) and every result array is copied back (D2H).
+    t0 = time.perf_counter()
+    for _ in range(2):
+        fe.run(fe.upload(frames)).to_host()
+    e2e = (time.perf_counter() - t0) / 2
+    in_bytes = sum(a.nbytes for fr in frames for a in fr)
+    out["end_to_end"] = {"value": F / e2e, "unit": "frames/s",
+                         "includes": "host-side concatenation, H2D of keypoints + descriptors "
+                                     f"({in_bytes / 1e6:.0f} MB), the pass, D2H of all result arrays",
+                         "seconds_per_pass": e2e}
+    if args.envelope_frames >= 2:
+        seq2 = StereoSequence(cam, n_frames=args.envelope_frames, n_features=(2000, 8000),
+                              seed=500 + rank, clutter=0.6)
+        fr2 = []
+        for k in range(args.envelope_frames):
+            f = seq2.frame(k)
+            fr2.append((f.kp_left, f.kp_right, f.des_left, f.des_right))
+        in2 = fe.upload(fr2)
+        fe.run(in2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            r2 = fe.run(in2)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+        i2 = r2.to_host()["ransac_info"].reshape(-1, 8)
+        nf = np.array([len(f[0]) for f in fr2])
+        out["envelope"] = {"value": args.envelope_frames / dt, "unit": "frames/s",
+                           "workload": f"{args.envelope_frames} frames with the feature count per image "
+                                       "drawn from U[2000, 8000] (ragged batch), otherwise as above",
+                           "features_per_image_mean": float(nf.mean()),
+                           "stereo_compares_per_frame_mean": float((nf.astype(np.float64) ** 2).mean()),
+                           "temporal_matches_mean": float(i2[:, 5].mean()),
+                           "ransac_iterations_mean": float(i2[:, 2].mean())}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_frontend(cam, frames[:7])
         out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     return out
+
+
+def bench_sweep(kernels):
+    """Matcher alone at the other sizes the workload family covers (one pair,
+    inputs resident): N in {2048, 4096, 8192} x D in {61 (AKAZE), 32 (ORB)}."""
+    from slam_amd.utils.synth import matcher_workload
+    rows = []
+    for nbytes in (61, 32):
+        for n in (2048, 4096, 8192):
+            qn, tn = matcher_workload(n, n, nbytes, seed=11)
+            q = kernels.to_device(qn, torch.uint8)
+            t = kernels.to_device(tn, torch.uint8)
+            out = (torch.empty((n, 2), dtype=torch.int32, device=q.device),
+                   torch.empty((n, 2), dtype=torch.int32, device=q.device),
+                   torch.empty(n, dtype=torch.uint8, device=q.device))
+            for _ in range(20):
+                kernels.hamming_knn2_ratio(q, t, RATIO, out=out)
+            torch.cuda.synchronize()
+            reps = 200
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                kernels.hamming_knn2_ratio(q, t, RATIO, out=out)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            ops = 2 * ((nbytes + 3) // 4)
+            rows.append({"n": n, "desc_bytes": nbytes, "us_per_call": dt * 1e6,
+                         "compares_per_sec": n * n / dt,
+                         "frac_of_measured_issue_rate": n * n * ops / dt / MEASURED_ISSUE_LANE_OPS})
+    return rows
 
 
 def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
@@ -243,6 +307,9 @@ def main():
     ap.add_argument("--frames", type=int, default=500,
                     help="frames per GPU of the secondary front-end measurement (0 = skip)")
     ap.add_argument("--frontend-steps", type=int, default=5)
+    ap.add_argument("--envelope-frames", type=int, default=60,
+                    help="frames of the 2000-8000 features/image front-end measurement (0 = skip)")
+    ap.add_argument("--no-sweep", action="store_true", help="skip the matcher size sweep")
     ap.add_argument("--lc-keyframes", type=int, default=270,
                     help="keyframes of the secondary loop-closure verification measurement (0 = skip)")
     args = ap.parse_args()
@@ -358,6 +425,8 @@ def main():
                                          "(profiles/r1/pmc_matcher8k.txt); includes the 4 MB of "
                                          "split results the kernel writes for the merge"},
         }
+        if world == 1 and not args.no_sweep:
+            line["sweep"] = bench_sweep(kernels)
         if frontend is not None:
             line["frontend"] = frontend
         if loop_verify is not None:

@@ -68,3 +68,53 @@ def save_relative_Rts(result, path: str = "relative_Rts") -> np.ndarray:
     with open(path, "wb") as fh:
         pickle.dump(rel, fh)
     return rel
+
+
+_FRAME_KEYS = ("pix_left", "pix_right", "xyz", "inlier_des_left")
+_PAIR_KEYS = ("query_idx", "train_idx", "dist", "mask")
+
+
+def save_records(result, path: str, n_frames: Optional[int] = None) -> str:
+    """Everything `replay_into_db` reads, as one `.npz` of concatenated arrays
+    plus per-frame / per-pair offsets, so that the replay into the reference's
+    TrackingDB can run later, in another process, without a GPU."""
+    if n_frames is None:
+        n_frames = result.n_frames if hasattr(result, "n_frames") else result.inputs.n_frames
+    frames = [result.frame(f) for f in range(n_frames)]
+    pairs = [result.pair(p) for p in range(max(n_frames - 1, 0))]
+    out = {"n_frames": np.int64(n_frames),
+           "frame_off": np.concatenate([[0], np.cumsum([len(f["pix_left"]) for f in frames])]).astype(np.int64),
+           "pair_off": np.concatenate([[0], np.cumsum([len(p["mask"]) for p in pairs])]).astype(np.int64)}
+    for k in _FRAME_KEYS:
+        out[k] = (np.concatenate([np.asarray(f[k]) for f in frames]) if frames
+                  else np.zeros((0,), np.float32))
+    for k in _PAIR_KEYS:
+        out[k] = (np.concatenate([np.asarray(p[k]) for p in pairs]) if pairs
+                  else np.zeros((0,), np.int32))
+    out["Rt"] = (np.stack([np.asarray(p["Rt"], dtype=np.float64) for p in pairs]) if pairs
+                 else np.zeros((0, 3, 4)))
+    np.savez(path, **out)
+    return path
+
+
+class SavedRecords:
+    """Read-back of `save_records` with the accessors `replay_into_db` uses."""
+
+    def __init__(self, path: str):
+        with np.load(path, allow_pickle=False) as z:
+            self._a = {k: z[k] for k in z.files}
+        self.n_frames = int(self._a["n_frames"])
+
+    def frame(self, f: int) -> dict:
+        lo, hi = self._a["frame_off"][f], self._a["frame_off"][f + 1]
+        return {k: self._a[k][lo:hi] for k in _FRAME_KEYS}
+
+    def pair(self, p: int) -> dict:
+        lo, hi = self._a["pair_off"][p], self._a["pair_off"][p + 1]
+        d = {k: self._a[k][lo:hi] for k in _PAIR_KEYS}
+        d["mask"] = d["mask"].astype(bool)
+        d["Rt"] = self._a["Rt"][p]
+        return d
+
+    def relative_Rts(self) -> np.ndarray:
+        return self._a["Rt"]

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
   accumulate(pts, pix, mask, n, pose, in, lds, sums);
 
   // lane 0 state
-  double H[21], g[6], cost = 0.0, lambda = 1e-6;
+  double H[21], g[6], cost = 0.0, lambda = 1e-6, last_step = 0.0;
   int iters = 0;
   if (threadIdx.x == 0) {
     for (int i = 0; i < 21; ++i) H[i] = sums[i];
@@ -163,13 +163,18 @@ __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
     if (threadIdx.x == 0) {
       double dx[6];
       bool ok = false;
+      last_step = 0.0;
       for (int tries = 0; tries < 8 && !ok; ++tries) {
         ok = solve_damped(H, g, lambda, dx);
         if (!ok) lambda = fmax(lambda * 10.0, 1e-6);
       }
       double step = 0.0;
       if (ok) for (int i = 0; i < 6; ++i) step = fmax(step, fabs(dx[i]));
-      if (!ok || step < 1e-13) {
+      last_step = step;
+      // Convergence is quadratic near the minimum: a step below 1e-10 (rad, m) means
+      // the pose already sits at it to that accuracy, so the pass that would only
+      // confirm it is not spent.
+      if (!ok || step < 1e-10) {
         ctrl[0] = 0;
       } else {
         double E[9];
@@ -195,10 +200,12 @@ __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
         for (int i = 0; i < 6; ++i) g[i] = sums[21 + i];
         cost = new_cost;
         lambda = fmax(lambda * 0.1, 1e-12);
-        ctrl[1] = rel < 1e-15 ? 0 : 1;
+        ctrl[1] = rel < 1e-14 ? 0 : 1;
       } else {
+        // a rejected step this small is rounding noise around the minimum, not a
+        // sign that more damping is needed
         lambda *= 10.0;
-        ctrl[1] = lambda > 1e12 ? 0 : 1;
+        ctrl[1] = (lambda > 1e12 || last_step < 1e-8) ? 0 : 1;
       }
     }
     __syncthreads();

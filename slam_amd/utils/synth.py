@@ -77,9 +77,16 @@ def _yaw(a: float) -> np.ndarray:
 class StereoSequence:
     """A corridor of static landmarks seen by a forward-moving stereo rig."""
 
-    def __init__(self, cam: CameraModel, n_frames: int, n_features: int = 1500, seed: int = 0,
+    def __init__(self, cam: CameraModel, n_frames: int, n_features=1500, seed: int = 0,
                  nbytes: int = 61, clutter: float = 0.35, pixel_sigma: float = 0.5,
                  bit_noise: float = 0.03):
+        """`n_features` is the number of keypoints per image: an int, or a (lo, hi)
+        pair for a per-frame count drawn uniformly from [lo, hi]."""
+        if isinstance(n_features, (tuple, list)):
+            self.n_features_range = (int(n_features[0]), int(n_features[1]))
+            n_features = self.n_features_range[1]
+        else:
+            self.n_features_range = None
         self.cam, self.n_frames, self.n_features = cam, n_frames, n_features
         self.nbytes, self.clutter = nbytes, clutter
         self.pixel_sigma, self.bit_noise, self.seed = pixel_sigma, bit_noise, seed
@@ -103,6 +110,9 @@ class StereoSequence:
     def frame(self, k: int) -> StereoFrame:
         rng = np.random.default_rng((self.seed + 1) * 1_000_003 + k)
         cam, Rt = self.cam, self.poses[k]
+        n_feat = self.n_features
+        if self.n_features_range is not None:
+            n_feat = int(rng.integers(self.n_features_range[0], self.n_features_range[1] + 1))
         Xc = self.land_xyz @ Rt[:, :3].T + Rt[:, 3]
         vis = (Xc[:, 2] > 4.0) & (Xc[:, 2] < 120.0)
         Xc, des = Xc[vis], self.land_des[vis]
@@ -114,14 +124,14 @@ class StereoSequence:
         inside = ((uvl[:, 0] > 0) & (uvl[:, 0] < IMG_W) & (uvl[:, 1] > 0) & (uvl[:, 1] < IMG_H) &
                   (uvr[:, 0] > 0) & (uvr[:, 0] < IMG_W))
         uvl, uvr, des = uvl[inside], uvr[inside], des[inside]
-        n_true = min(len(uvl), int(self.n_features * (1 - self.clutter)))
+        n_true = min(len(uvl), int(n_feat * (1 - self.clutter)))
         sel = rng.permutation(len(uvl))[:n_true]
         uvl, uvr, des = uvl[sel], uvr[sel], des[sel]
         uvl = uvl + rng.normal(0, self.pixel_sigma, uvl.shape)
         uvr = uvr + rng.normal(0, self.pixel_sigma, uvr.shape)
         des_l = flip_bits(rng, des, self.bit_noise)
         des_r = flip_bits(rng, des, self.bit_noise)
-        n_cl = self.n_features - n_true
+        n_cl = n_feat - n_true
 
         def clutter_pts(n):
             return np.column_stack([rng.uniform(0, IMG_W, n), rng.uniform(0, IMG_H, n)])

@@ -73,3 +73,22 @@ def test_replay_into_db_and_relative_rts(tmp_path):
         back = pickle.load(fh)
     np.testing.assert_array_equal(back, np.stack([p["Rt"] for p in pairs]))
     assert rel.shape == (4, 3, 4)
+
+
+def test_saved_records_replay_like_the_live_result(tmp_path):
+    rng = np.random.default_rng(2)
+    frames, pairs = _records(rng, 4)
+    seq = sharding.merge_records([sharding.pack_records(frames, pairs, 0, 0, 61)], 4)
+    path = db_adapter.save_records(seq, str(tmp_path / "rec.npz"))
+    back = db_adapter.SavedRecords(path)
+    assert back.n_frames == 4
+    a = db_adapter.replay_into_db(RecordingDB(), seq)
+    b = db_adapter.replay_into_db(RecordingDB(), back)
+    for (la, da, ma, ia), (lb, dbb, mb, ib) in zip(a.calls, b.calls):
+        assert [(l.x_left, l.x_right, l.y) for l in la] == [(l.x_left, l.x_right, l.y) for l in lb]
+        np.testing.assert_array_equal(da, dbb)
+        if ma is not None:
+            assert [(m.queryIdx, m.trainIdx, m.distance) for m in ma] == \
+                   [(m.queryIdx, m.trainIdx, m.distance) for m in mb]
+            np.testing.assert_array_equal(ia, ib)
+    np.testing.assert_array_equal(back.relative_Rts(), seq.relative_Rts)

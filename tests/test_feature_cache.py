@@ -1,0 +1,57 @@
+"""CPU tests of the on-disk feature cache (one .npz per frame)."""
+import numpy as np
+import pytest
+
+from slam_amd.backend.tracking import feature_cache as fc
+
+
+def _frame(rng, nl, nr, d=61):
+    return (rng.uniform(0, 1200, (nl, 2)).astype(np.float32), rng.uniform(0, 1200, (nr, 2)).astype(np.float32),
+            rng.integers(0, 256, (nl, d), dtype=np.uint8), rng.integers(0, 256, (nr, d), dtype=np.uint8))
+
+
+def test_roundtrip_slicing_and_laziness(tmp_path):
+    rng = np.random.default_rng(0)
+    frames = [_frame(rng, 10 + k, 7 + k) for k in range(5)]
+    frames.append(_frame(rng, 0, 0))                       # an image with no features at all
+    fc.write_sequence(str(tmp_path), frames)
+    cache = fc.FeatureCache(str(tmp_path))
+    assert len(cache) == 6
+    for k in (0, 3, -1):
+        for a, b in zip(cache[k], frames[k]):
+            np.testing.assert_array_equal(a, b)
+            assert a.dtype == b.dtype and a.flags.c_contiguous
+    part = cache[2:4]
+    assert len(part) == 2
+    np.testing.assert_array_equal(part[1][2], frames[3][2])
+    assert len(fc.FeatureCache(str(tmp_path), max_frames=3)) == 3
+    with pytest.raises(IndexError):
+        cache[6]
+
+
+def test_keypoint_objects_and_validation(tmp_path):
+    class KP:
+        def __init__(self, x, y):
+            self.pt = (x, y)
+    rng = np.random.default_rng(1)
+    _, _, dl, dr = _frame(rng, 3, 2)
+    fc.save_frame(str(tmp_path), 0, [KP(1, 2), KP(3, 4), KP(5, 6)], [KP(7, 8), KP(9, 10)], dl, dr)
+    kl, kr, _, _ = fc.FeatureCache(str(tmp_path))[0]
+    assert kl.tolist() == [[1, 2], [3, 4], [5, 6]] and kr.tolist() == [[7, 8], [9, 10]]
+    with pytest.raises(ValueError):
+        fc.save_frame(str(tmp_path), 1, np.zeros((3, 2)), np.zeros((2, 2)), dl[:2], dr)   # rows != keypoints
+    with pytest.raises(ValueError):
+        fc.save_frame(str(tmp_path), 1, np.zeros((3, 2)), np.zeros((2, 2)), dl, dr[:, :32])  # D differs
+
+
+def test_gaps_and_missing_directory(tmp_path):
+    rng = np.random.default_rng(2)
+    fc.save_frame(str(tmp_path), 0, *_frame(rng, 2, 2))
+    fc.save_frame(str(tmp_path), 2, *_frame(rng, 2, 2))
+    with pytest.raises(ValueError):
+        fc.FeatureCache(str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        fc.FeatureCache(str(tmp_path / "nope"))
+    (tmp_path / "empty").mkdir()
+    with pytest.raises(FileNotFoundError):
+        fc.FeatureCache(str(tmp_path / "empty"))

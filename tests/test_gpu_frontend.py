@@ -1,5 +1,7 @@
 """GPU parity test of the batched front-end against the frame-at-a-time CPU
 restatement of fill_database.py's data flow."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -170,3 +172,31 @@ def test_sharded_run_two_ranks_equals_single_rank():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)], results
+
+
+def test_run_sequence_tool_from_feature_cache(tmp_path):
+    """tools/run_sequence.py end to end on a synthesised cache: the pickled poses
+    and the saved records equal what the front-end returns for the same frames."""
+    import pickle
+    import subprocess
+    import sys
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking import db_adapter, feature_cache
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    feats, out = str(tmp_path / "features"), str(tmp_path / "out")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sequence.py"), "--features", feats,
+                        "--out", out, "--synthesize", "6"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "5 relative poses" in r.stdout
+    with open(os.path.join(out, "relative_Rts"), "rb") as fh:
+        rel = pickle.load(fh)
+    assert rel.shape == (5, 3, 4) and rel.dtype == np.float64
+    cache = feature_cache.FeatureCache(feats)
+    res = TrackingFrontend(CameraModel.kitti_like(), seed=0).run(cache[0:6])
+    np.testing.assert_array_equal(rel, res.relative_Rts())
+    back = db_adapter.SavedRecords(os.path.join(out, "frontend_records.npz"))
+    for f in range(6):
+        np.testing.assert_array_equal(back.frame(f)["pix_left"], res.frame(f)["pix_left"])
+    for p in range(5):
+        np.testing.assert_array_equal(back.pair(p)["mask"], res.pair(p)["mask"])
