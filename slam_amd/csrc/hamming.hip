@@ -63,14 +63,19 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
   const unsigned r = g >> log2W;
   const int w = (int)(g & ((1u << log2W) - 1u));
   const uint8_t *p = src + (size_t)r * (size_t)stride + 4 * w;
-  const int valid = desc_bytes - 4 * w;  // bytes of this dword that belong to the row
+  const int valid = min(4, desc_bytes - 4 * w);  // bytes of this dword that belong to the row
   uint32_t v = 0;
-  if (valid >= 4 && (((uintptr_t)p) & 3u) == 0) {
-    v = *reinterpret_cast<const uint32_t *>(p);
-  } else {
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-      if (b < valid) v |= (uint32_t)p[b] << (8 * b);
+  if (valid > 0) {
+    // Rows of 61 bytes start at any byte offset: fetch the one or two aligned dwords
+    // that hold the wanted bytes and funnel-shift.  Each of them contains a byte of
+    // the row, so neither can lie on a page the row does not touch.
+    const uintptr_t a = (uintptr_t)p;
+    const unsigned sh = (unsigned)(a & 3u);
+    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a - sh);
+    const uint32_t lo = pa[0];
+    const uint32_t hi = ((int)sh + valid > 4) ? pa[1] : 0u;
+    v = __builtin_amdgcn_alignbyte(hi, lo, sh);
+    if (valid < 4) v &= (1u << (8 * valid)) - 1u;
   }
   dst[g] = v;
 }
@@ -462,7 +467,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
   if (g_prof.enabled && g_prof.used < g_prof.pool.size()) {
     ev = &g_prof.pool[g_prof.used++];
-    hipEventRecord(ev->first, st);
+    (void)hipEventRecord(ev->first, st);
   }
   const int nqs = d_q_off ? 0 : nq_total, nts = d_q_off ? 0 : nt_total;
 #define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
@@ -478,7 +483,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     if (p.use_lds) SLAMHIP_DISPATCH(32, 1, true); else SLAMHIP_DISPATCH(32, 1, false);
   }
 #undef SLAMHIP_DISPATCH
-  if (ev) hipEventRecord(ev->second, st);
+  if (ev) (void)hipEventRecord(ev->second, st);
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.splits > 1) {

@@ -28,18 +28,18 @@ using namespace slamhip_dev;
 constexpr int kBlock = 256;
 
 // --------------------------------------------------------------------------
-// Stereo stage: filter + stable compaction + triangulation + gathers.
-// One workgroup per frame walks the sorted matches in chunks of 256.
+// Stereo stage, first half: row/disparity filter + stable compaction (ballot
+// prefix) of the sorted matches.  One workgroup per frame walks them in chunks
+// of 256 so that the survivors keep their order.
 // --------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
     const float *__restrict__ kp_left, const float *__restrict__ kp_right,
     const int32_t *__restrict__ off_left, const int32_t *__restrict__ off_right,
     const int32_t *__restrict__ idx2, const int32_t *__restrict__ dist2,
-    const int32_t *__restrict__ order, const uint32_t *__restrict__ packed_left, int W, CamPair cam,
-    double pix_thresh, double disp_min, int32_t *__restrict__ st_count,
-    int32_t *__restrict__ st_left, int32_t *__restrict__ st_right, int32_t *__restrict__ st_dist,
-    float *__restrict__ st_xyz, float *__restrict__ st_pix_left, float *__restrict__ st_pix_right,
-    uint32_t *__restrict__ st_desc) {
+    const int32_t *__restrict__ order, double pix_thresh, double disp_min,
+    int32_t *__restrict__ st_count, int32_t *__restrict__ st_left, int32_t *__restrict__ st_right,
+    int32_t *__restrict__ st_dist, float *__restrict__ st_pix_left,
+    float *__restrict__ st_pix_right) {
   __shared__ int wave_tot[kBlock / 64];
   __shared__ int running;
   const int f = blockIdx.x;
@@ -76,16 +76,10 @@ __global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
     }
     const int pos = running + wave_base + prefix;
     if (keep) {
-      double x[4];
-      dlt_null_vector(cam, uL, vL, uR, vR, x);
-      const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
       const size_t o = (size_t)(base + pos);
       st_left[o] = q;
       st_right[o] = t;
       st_dist[o] = d;
-      st_xyz[3 * o + 0] = x0 / x3;
-      st_xyz[3 * o + 1] = x1 / x3;
-      st_xyz[3 * o + 2] = x2 / x3;
       st_pix_left[2 * o + 0] = (float)uL;
       st_pix_left[2 * o + 1] = (float)vL;
       st_pix_right[2 * o + 0] = (float)uR;
@@ -95,13 +89,38 @@ __global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
     if (threadIdx.x == 0) running += chunk_total;
     __syncthreads();
   }
-  const int m = running;
-  if (threadIdx.x == 0) st_count[f] = m;
-  // descriptor rows of the inliers, in inlier order (global writes above are
-  // visible to the whole workgroup after the barriers)
-  for (int e = threadIdx.x; e < m * W; e += kBlock) {
-    const int i = e / W, w = e - i * W;
-    st_desc[(size_t)(base + i) * W + w] = packed_left[(size_t)(base + st_left[base + i]) * W + w];
+  if (threadIdx.x == 0) st_count[f] = running;
+}
+
+// Second half of the stereo stage, over the compacted inliers only (every lane
+// has work): DLT triangulation of inlier i of frame f from its two pixels, and
+// the gather of its packed left descriptor row.  grid = (chunks of 256, frames).
+__global__ __launch_bounds__(kBlock) void stereo_points_kernel(
+    const int32_t *__restrict__ off_left, const int32_t *__restrict__ st_count,
+    const int32_t *__restrict__ st_left, const float *__restrict__ st_pix_left,
+    const float *__restrict__ st_pix_right, const uint32_t *__restrict__ packed_left, int W,
+    CamPair cam, float *__restrict__ st_xyz, uint32_t *__restrict__ st_desc) {
+  const int f = blockIdx.y;
+  const int base = off_left[f], m = st_count[f];
+  const int i0 = blockIdx.x * kBlock;
+  if (i0 >= m) return;
+  const int i = i0 + (int)threadIdx.x;
+  if (i < m) {
+    const size_t o = (size_t)(base + i);
+    double x[4];
+    dlt_null_vector(cam, (double)st_pix_left[2 * o], (double)st_pix_left[2 * o + 1],
+                    (double)st_pix_right[2 * o], (double)st_pix_right[2 * o + 1], x);
+    const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
+    st_xyz[3 * o + 0] = x0 / x3;
+    st_xyz[3 * o + 1] = x1 / x3;
+    st_xyz[3 * o + 2] = x2 / x3;
+  }
+  // descriptor rows of this block's inliers, in inlier order (W is a power of two)
+  const int rows = min(kBlock, m - i0);
+  const int lw = W == 8 ? 3 : (W == 16 ? 4 : 5);
+  for (int e = threadIdx.x; e < rows * W; e += kBlock) {
+    const int r = i0 + (e >> lw), w = e & (W - 1);
+    st_desc[(size_t)(base + r) * W + w] = packed_left[(size_t)(base + st_left[base + r]) * W + w];
   }
 }
 
@@ -532,9 +551,12 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   CamPair cam;
   for (int i = 0; i < 12; ++i) { cam.PL[i] = a->P_left[i]; cam.PR[i] = a->P_right[i]; }
   hipLaunchKernelGGL(stereo_compact_kernel, dim3(F), dim3(kBlock), 0, st, a->d_kp_left,
-                     a->d_kp_right, a->d_off_left, a->d_off_right, idx2, dist2, order, packL, W, cam,
+                     a->d_kp_right, a->d_off_left, a->d_off_right, idx2, dist2, order,
                      a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
-                     a->d_st_dist, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_st_desc);
+                     a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
+  hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F), dim3(kBlock),
+                     0, st, a->d_off_left, a->d_st_count, a->d_st_left, a->d_st_pix_left,
+                     a->d_st_pix_right, packL, W, cam, a->d_st_xyz, a->d_st_desc);
   SLAMHIP_CHECK_LAUNCH();
   if (F < 2) return SLAMHIP_OK;
 
