@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
     const float *__restrict__ cx, const float *__restrict__ cpl,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
     int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info) {
-  __shared__ int sh[2];  // stopped, winner lane of the replayed round
+  __shared__ int sh[3];  // stopped, winner lane of the replayed round, iterations required
   const int p = blockIdx.x;
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
@@ -245,6 +245,7 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
     }
     sh[0] = s[7];
     sh[1] = winner;
+    sh[2] = s[3];
   }
   __syncthreads();
   if (threadIdx.x < 12) {
@@ -257,8 +258,10 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
   if (sh[0]) return;
   __syncthreads();  // the winner has been read before its slot is overwritten
 
+  // The required iteration count only ever shrinks, so a hypothesis at or beyond the
+  // current requirement can never be consumed by the replay: it is not generated.
   const int it = round * kHypPerRound + (int)threadIdx.x;
-  const bool active = it < prm.n_iter_max;
+  const bool active = it < prm.n_iter_max && it < sh[2];
   bool valid = false;
   if (active) {
     const float *X = cx + 3 * (size_t)obase[p];
