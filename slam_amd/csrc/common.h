@@ -28,6 +28,10 @@ static inline int slamhip_packed_words(int desc_bytes) {
 
 // Cross-translation-unit entry points (not part of the C ABI).
 namespace slamhip_internal {
+// 1: consensus counting screens in packed fp32 and re-evaluates undecided points in
+// fp64 (same counts); 0: fp64 only.  Set through slamhip_tune(2, value).
+extern int g_ransac_screen;
+
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                             int desc_bytes, long long n_out = -1, bool prepacked = false);
 // Batched top-2 matcher.  prepacked: rows are already W-dword packed (row_stride

@@ -504,10 +504,12 @@ extern "C" {
 
 // Diagnostics knob used by the kernel-variant benchmark: knob 0 = kernel
 // variant (-1 auto; bit0 LDS-staged train tile, value>>1 = queries per lane),
-// knob 1 = forced number of train splits (0 auto).
+// knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
+// screening in the consensus counting kernels (1 on, 0 fp64 only; same counts).
 int slamhip_tune(int knob, int value) {
   if (knob == 0) g_force_variant = value;
   else if (knob == 1) g_force_splits = value;
+  else if (knob == 2) slamhip_internal::g_ransac_screen = value ? 1 : 0;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
 }

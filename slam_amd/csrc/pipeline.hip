@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span) {
+    const int32_t *__restrict__ info, int chunks_per_span, int screened) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p = blockIdx.z;
   if (info[8 * (size_t)p + 7]) return;
@@ -332,22 +332,34 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
       Rt[i] = valid ? rt[((size_t)p * 12 + i) * kHypPerRound + hyp] : 0.0;
     make_projections(Rt, cam, PL, PR);
   }
+  Hyp32 h32;
+  if (screened) make_hyp32(PL, PR, h32);
   const double thr2 = thresh * thresh;
+  float *ldsf = reinterpret_cast<float *>(lds);
   int c = 0;
   for (int p0 = span0; p0 < span1; p0 += kPtsPerChunk) {
     const size_t base = (size_t)obase[p] + p0;
     const int cnt = min(kPtsPerChunk, span1 - p0);
     if (p0 != span0) __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += 64) {
-      const size_t g = base + i;
-      double *o = lds + i * kPtStride;
-      o[0] = (double)cx[3 * g]; o[1] = (double)cx[3 * g + 1]; o[2] = (double)cx[3 * g + 2];
-      o[3] = (double)cpl[2 * g]; o[4] = (double)cpl[2 * g + 1];
-      o[5] = (double)cpr[2 * g]; o[6] = (double)cpr[2 * g + 1];
-      o[7] = 0.0;
+    if (screened) {
+      for (int j = threadIdx.x; 2 * j < cnt; j += 64) {
+        const size_t a = base + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
+        stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b);
+      }
+    } else {
+      for (int i = threadIdx.x; i < cnt; i += 64) {
+        const size_t g = base + i;
+        double *o = lds + i * kPtStride;
+        o[0] = (double)cx[3 * g]; o[1] = (double)cx[3 * g + 1]; o[2] = (double)cx[3 * g + 2];
+        o[3] = (double)cpl[2 * g]; o[4] = (double)cpl[2 * g + 1];
+        o[5] = (double)cpr[2 * g]; o[6] = (double)cpr[2 * g + 1];
+        o[7] = 0.0;
+      }
     }
     __syncthreads();
-    if (valid) c += count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
+    if (valid)
+      c += screened ? count_chunk_inliers_screened(ldsf, cnt, PL, PR, h32, thresh, thr2)
+                    : count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
   }
   if (valid && c) atomicAdd(slot, c);
 }
@@ -436,7 +448,7 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       hipLaunchKernelGGL(ransac_count_kernel,
                          dim3(slamhip_ceil_div(chunks, per_span), kHypPerRound / 64, np), dim3(64), 0,
                          st, obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,
-                         info + 8 * (size_t)g0, per_span);
+                         info + 8 * (size_t)g0, per_span, slamhip_internal::g_ransac_screen);
     }
     hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds, obase + g0,
                        tm_count + g0, cx, cpl, cpr, prm, rt, counts, pose_ransac + 12 * (size_t)g0,

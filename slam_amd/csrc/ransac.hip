@@ -20,6 +20,8 @@
 // the literal formula's decision on the same projection values.
 #include "common.h"
 
+#include <type_traits>
+
 #include "ransac_device.h"
 
 namespace {
@@ -49,11 +51,20 @@ template <typename PT>
 __global__ __launch_bounds__(64) void ransac_score_kernel(
     const PT *__restrict__ pts, const float *__restrict__ mL, const float *__restrict__ mR, int n,
     const double *__restrict__ Rt, const uint8_t *__restrict__ valid, int h, RansacCam cam,
-    double thr, int32_t *__restrict__ counts) {
+    double thr, int32_t *__restrict__ counts, int screened) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p0 = blockIdx.y * kPtsPerChunk;
   const int cnt = min(kPtsPerChunk, n - p0);
-  stage_points(lds, pts, mL, mR, p0, cnt);
+  constexpr bool kCanScreen = std::is_same<PT, float>::value;  // exact fp32 points only
+  if (kCanScreen && screened) {
+    float *ldsf = reinterpret_cast<float *>(lds);
+    for (int j = threadIdx.x; 2 * j < cnt; j += blockDim.x) {
+      const size_t a = (size_t)p0 + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
+      stage_pair(ldsf + j * kPairStride, reinterpret_cast<const float *>(pts), mL, mR, a, b);
+    }
+  } else {
+    stage_points(lds, pts, mL, mR, p0, cnt);
+  }
   __syncthreads();
 
   const int hyp = blockIdx.x * 64 + threadIdx.x;
@@ -65,7 +76,14 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(
   double PL[12], PR[12];
   make_projections(Rt + 12 * (size_t)hyp, cam, PL, PR);
   const double thr2 = thr * thr;
-  const int c = count_chunk_inliers(lds, cnt, PL, PR, thr, thr2);
+  int c;
+  if (kCanScreen && screened) {
+    Hyp32 h32;
+    make_hyp32(PL, PR, h32);
+    c = count_chunk_inliers_screened(reinterpret_cast<const float *>(lds), cnt, PL, PR, h32, thr, thr2);
+  } else {
+    c = count_chunk_inliers(lds, cnt, PL, PR, thr, thr2);
+  }
   if (gridDim.y == 1) counts[hyp] = c;
   else if (c != 0) atomicAdd(&counts[hyp], c);
 }
@@ -170,6 +188,8 @@ void fill_cam(RansacCam &cam, const double *K, const double *M_right) {
 
 }  // namespace
 
+int slamhip_internal::g_ransac_screen = 1;
+
 extern "C" {
 
 int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_meas_l,
@@ -193,10 +213,11 @@ int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_m
   const dim3 grid(slamhip_ceil_div(h, 64), chunks), block(64);
   if (points_fp64)
     hipLaunchKernelGGL(ransac_score_kernel<double>, grid, block, 0, st, (const double *)d_points,
-                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts);
+                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts, 0);
   else
     hipLaunchKernelGGL(ransac_score_kernel<float>, grid, block, 0, st, (const float *)d_points,
-                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts);
+                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts,
+                       slamhip_internal::g_ransac_screen);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

@@ -145,3 +145,49 @@ def test_pnp_facade_with_injected_hypotheses():
     s = pnp.supporters_pair(mL, so.project(X, P), mR, so.project(X, cam.K @ Rt_R))
     np.testing.assert_array_equal(s, so.supporters_pair(mL, so.project(X, P), mR,
                                                         so.project(X, cam.K @ Rt_R), 4.0))
+
+
+def test_packed_fp32_screening_never_changes_a_count():
+    """The counting kernels screen in packed fp32 and hand every undecided point
+    to the fp64 path; with the screen switched off (tune knob 2) the same calls must
+    return identical counts.  The scene is built to stress the bound: measurements
+    placed exactly on, and a few ulps either side of, the threshold circle of the
+    true pose; near (2 m) and far (400 m) points; points behind the camera and at
+    w ~ 0; hypotheses from exact to wild, including NaN."""
+    from slam_amd import kernels, CameraModel, _lib
+    from slam_amd.utils.synth import perturbed_hypotheses
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(21)
+    n, H, thr = 3001, 6000, 2.0
+    X = np.column_stack([rng.uniform(-40, 40, n), rng.uniform(-5, 5, n), rng.uniform(2, 400, n)])
+    X[:40, 2] = rng.uniform(-5, 0.5, 40)            # behind / at the camera plane
+    X = X.astype(np.float32)
+    Rt = np.hstack([np.eye(3), np.array([[0.03], [-0.01], [-0.8]])])
+    Rr = so.homogenous(cam.M_right) @ so.homogenous(Rt)
+    pL = so.project(X.astype(np.float64), cam.K @ Rt)
+    pR = so.project(X.astype(np.float64), cam.K @ Rr[:3])
+    phi = rng.uniform(0, 2 * np.pi, n)
+    rad = np.where(rng.random(n) < 0.5, thr, rng.uniform(0, 2 * thr, n))   # half exactly on the circle
+    mL = (pL + (rad * np.array([np.cos(phi), np.sin(phi)])).T).astype(np.float32)
+    mR = (pR + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
+    for k in range(0, 600, 3):                      # nudge some by single float32 ulps
+        mL[k, 0] = np.nextafter(mL[k, 0], np.float32(np.inf if k % 2 else -np.inf))
+    Rts, valid = perturbed_hypotheses(rng, Rt, H, good_fraction=0.5)
+    Rts[0] = Rt
+    Rts[1, 2, 3] = 0.0                              # t_z = 0: w ~ Z
+    Rts[2] = np.nan
+    Rts[3] *= 1e6                                   # overflows fp32 squares
+    valid[:4] = 1
+    try:
+        assert _lib.lib.slamhip_tune(2, 0) == 0
+        ref = kernels.ransac_score(X, mL, mR, Rts, valid, cam.K, cam.M_right, thr).cpu().numpy()
+        assert _lib.lib.slamhip_tune(2, 1) == 0
+        got = kernels.ransac_score(X, mL, mR, Rts, valid, cam.K, cam.M_right, thr).cpu().numpy()
+    finally:
+        _lib.lib.slamhip_tune(2, 1)
+    np.testing.assert_array_equal(got, ref)
+    assert ref[0] > 0 and (ref[valid == 0] == -1).all() and ref[2] == 0
+    # and against the reference arithmetic, outside the stated band
+    eL, eR = so.hypothesis_errors(cam.K, cam.M_right, Rts[0], X, mL, mR)
+    sure = (np.abs(eL - thr) > BAND) & (np.abs(eR - thr) > BAND)
+    assert abs(int(((eL <= thr) & (eR <= thr))[sure].sum()) - int(ref[0])) <= int((~sure).sum())

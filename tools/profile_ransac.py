@@ -40,7 +40,12 @@ def timed(fn, reps=5):
     return (time.perf_counter() - t0) / reps, out
 
 
+from slam_amd import _lib
 t_p3p, (Rts, valid) = timed(lambda: kernels.p3p_solve_indexed(Xd, pld, ixd, cam.K))
 t_sc, counts = timed(lambda: kernels.ransac_score(Xd, pld, prd, Rts, valid, cam.K, cam.M_right, 2.0))
-print(f"h={h} n={n}: p3p {t_p3p*1e6:.0f} us ({int(valid.sum())} valid), score {t_sc*1e6:.0f} us, "
+_lib.lib.slamhip_tune(2, 0)          # fp64 only
+t_64, counts64 = timed(lambda: kernels.ransac_score(Xd, pld, prd, Rts, valid, cam.K, cam.M_right, 2.0))
+_lib.lib.slamhip_tune(2, 1)
+print(f"h={h} n={n}: p3p {t_p3p*1e6:.0f} us ({int(valid.sum())} valid), score {t_sc*1e6:.0f} us "
+      f"(fp64 only: {t_64*1e6:.0f} us, same counts: {bool((counts == counts64).all())}), "
       f"best count {int(counts.max())}")
