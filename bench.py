@@ -250,6 +250,7 @@ def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
         dist.barrier()
     t0 = time.perf_counter()
     res = ver.verify(pairs)
+    vm = res.verified_matches()        # matches + inlier masks of the verified pairs, on the host
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -267,8 +268,10 @@ def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
             "verified_on_rank0": int(res["ok"].sum()), "pairs_on_rank0": int(len(pairs)),
             "ransac_iterations_mean_rank0": float(res["iterations"].mean()),
             "workload": "all-pairs keyframe verification (match k=1 + sort, P3P RANSAC <=1500 iters at "
-                        "1.5 px with stereo consensus, LM refinement), results copied to the host; "
-                        "time includes the per-call H2D of the pair tables and D2H of the results"}
+                        "1.5 px with stereo consensus, LM refinement); time includes the per-call H2D "
+                        "of the pair tables and D2H of every pair's flag / pose / counts and of the "
+                        "matches and inlier masks of the verified pairs",
+            "verified_match_rows_rank0": int(vm["off"][-1])}
 
 
 def cpu_baseline_frontend(cam, frames):

@@ -17,6 +17,71 @@ from ... import _lib, kernels
 from ..._lib import lib, check, VerifyArgs
 
 
+class VerifyResult(dict):
+    """Result of PairVerifier.verify.  The per-pair arrays (ok, Rt, Rt_ransac,
+    n_matches, n_inliers, iterations, out_off) are host arrays.  The per-match
+    arrays (query_idx, train_idx, dist, mask; and xyz per keyframe row) stay on
+    the device until asked for: `res["mask"]` copies the whole array once,
+    `res.pair_matches(p)` copies one pair, `res.verified_matches()` gathers the
+    rows of all verified pairs on the device and copies only those.  Almost all
+    candidate pairs of an all-pairs screen fail, so the consumer of the verified
+    pairs (loop_closure.py:226-235) never needs the rest."""
+
+    _LAZY = {"query_idx": ("tm_query", None), "train_idx": ("tm_train", None),
+             "dist": ("tm_dist", None), "mask": ("tm_mask", bool), "xyz": ("xyz", None)}
+
+    def __init__(self, host: dict, device: dict, n_out: int, n_rows: int):
+        super().__init__(host)
+        self._dev, self._n_out, self._n_rows = device, n_out, n_rows
+
+    def __missing__(self, key):
+        if key not in self._LAZY:
+            raise KeyError(key)
+        name, cast = self._LAZY[key]
+        a = self._dev[name].cpu().numpy()
+        a = a.reshape(-1, 3)[:self._n_rows] if key == "xyz" else a[:self._n_out]
+        if cast is not None:
+            a = a.astype(cast)
+        self[key] = a
+        return a
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._LAZY
+
+    def pair_matches(self, p: int) -> dict:
+        lo, hi = int(self["out_off"][p]), int(self["out_off"][p + 1])
+        out = {}
+        for key, (name, cast) in self._LAZY.items():
+            if key == "xyz":
+                continue
+            a = self._dev[name][lo:hi].cpu().numpy()
+            out[key] = a.astype(cast) if cast is not None else a
+        return out
+
+    def verified_matches(self) -> dict:
+        """{"pairs": indices of verified pairs, "off": (len+1,) offsets, and the
+        per-match arrays of just those pairs, concatenated in that order}."""
+        idx = np.flatnonzero(self["ok"])
+        start = self["out_off"][idx].astype(np.int64)
+        count = (self["out_off"][idx + 1] - self["out_off"][idx]).astype(np.int64)
+        off = np.concatenate([[0], np.cumsum(count)]).astype(np.int64)
+        out = {"pairs": idx, "off": off}
+        dev = self._dev["tm_query"].device
+        if len(idx):
+            seg = torch.repeat_interleave(torch.arange(len(idx), device=dev),
+                                          torch.from_numpy(count).to(dev))
+            rows = (torch.from_numpy(start).to(dev)[seg] +
+                    (torch.arange(int(off[-1]), device=dev) - torch.from_numpy(off[:-1]).to(dev)[seg]))
+        else:
+            rows = torch.zeros(0, dtype=torch.int64, device=dev)
+        for key, (name, cast) in self._LAZY.items():
+            if key == "xyz":
+                continue
+            a = self._dev[name][rows].cpu().numpy()
+            out[key] = a.astype(cast) if cast is not None else a
+        return out
+
+
 class PairVerifier:
     """Defaults follow the reference: PnP pixel threshold 1.5 px and
     min_inliers_loop (loop_closure.py:24-32), p_success 0.99999 and
@@ -52,9 +117,11 @@ class PairVerifier:
 
     def verify(self, pairs) -> dict:
         """pairs: (P,2) int array of (candidate, current) keyframe indices.
-        Returns a dict of host arrays: ok (P,), Rt (P,3,4) candidate->current
-        pose, Rt_ransac, n_matches, n_inliers, iterations, out_off (P+1,), and the
-        flat per-match arrays query_idx / train_idx / dist / mask."""
+        Returns a VerifyResult: ok (P,), Rt (P,3,4) candidate->current pose,
+        Rt_ransac, n_matches, n_inliers, iterations, out_off (P+1,) on the host,
+        and the flat per-match arrays query_idx / train_idx / dist / mask (rows
+        out_off[p]:out_off[p+1] belong to pair p), copied from the device on
+        first use."""
         if self._kf is None:
             raise RuntimeError("call set_keyframes first")
         kf = self._kf
@@ -112,11 +179,10 @@ class PairVerifier:
         info = out["info"].cpu().numpy().reshape(-1, 8)[:P]
         n_matches, n_inl = info[:, 5], info[:, 6]
         ok = (n_matches >= self.min_inliers) & (n_inl >= self.min_inliers) & (info[:, 0] >= 0)
-        return {
+        host = {
             "ok": ok, "Rt": out["pose_refined"].cpu().numpy().reshape(-1, 3, 4)[:P],
             "Rt_ransac": out["pose_ransac"].cpu().numpy().reshape(-1, 3, 4)[:P],
             "n_matches": n_matches, "n_inliers": n_inl, "iterations": info[:, 2],
-            "out_off": obase, "xyz": out["xyz"].cpu().numpy().reshape(-1, 3)[:N],
-            "query_idx": out["tm_query"].cpu().numpy()[:O], "train_idx": out["tm_train"].cpu().numpy()[:O],
-            "dist": out["tm_dist"].cpu().numpy()[:O], "mask": out["tm_mask"].cpu().numpy()[:O].astype(bool),
+            "out_off": obase,
         }
+        return VerifyResult(host, out, O, N)

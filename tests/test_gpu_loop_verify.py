@@ -73,3 +73,31 @@ def test_verify_pairs_edge_cases():
     assert res["n_matches"].tolist() == [10, 0, 0, 80]
     assert res["iterations"][0] == 0          # fewer than min_inliers_loop matches: not attempted
     assert ver.verify(np.zeros((0, 2), int))["ok"].shape == (0,)
+
+
+def test_lazy_match_arrays_agree():
+    """pair_matches(p) and verified_matches() return the same rows as the full
+    per-match arrays."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=12, n_features=500, seed=3, clutter=0.4)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in (0, 1, 2, 9))]
+    st = TrackingFrontend(cam, n_iter_max=1).run(frames)
+    kfs = [(st.frame(k)["links"], st.frame(k)["inlier_des_left"]) for k in range(4)]
+    ver = PairVerifier(cam, min_inliers_loop=40, seed=1).set_keyframes(kfs)
+    res = ver.verify([(0, 1), (0, 3), (1, 2), (2, 3)])
+    assert res["ok"][0] and res["ok"][2]
+    vm = res.verified_matches()
+    assert vm["pairs"].tolist() == np.flatnonzero(res["ok"]).tolist()
+    for k, p in enumerate(vm["pairs"]):
+        one = res.pair_matches(int(p))
+        sl = slice(int(res["out_off"][p]), int(res["out_off"][p + 1]))
+        vs = slice(int(vm["off"][k]), int(vm["off"][k + 1]))
+        for key in ("query_idx", "train_idx", "dist", "mask"):
+            assert key in res
+            np.testing.assert_array_equal(one[key], res[key][sl])
+            np.testing.assert_array_equal(vm[key][vs], res[key][sl])
+        assert one["mask"].dtype == bool and one["mask"].sum() == res["n_inliers"][p]
