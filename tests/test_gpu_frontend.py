@@ -200,3 +200,44 @@ def test_run_sequence_tool_from_feature_cache(tmp_path):
         np.testing.assert_array_equal(back.frame(f)["pix_left"], res.frame(f)["pix_left"])
     for p in range(5):
         np.testing.assert_array_equal(back.pair(p)["mask"], res.pair(p)["mask"])
+
+
+def test_ransac_rounds_equal_stand_alone_kernels():
+    """The batched RANSAC (rounds of 256 hypotheses, late rounds on the narrow
+    grid, hypotheses beyond the current requirement not generated) against the
+    same samples pushed through the stand-alone kernels one pair at a time:
+    P3P -> consensus counts -> sequential replay.  Same device arithmetic, so
+    winner, count, iteration trace, pose and mask must agree exactly, for pairs
+    that stop in different rounds and an iteration cap that is not a multiple of
+    the round size."""
+    from slam_amd import CameraModel, kernels
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=7, n_features=900, seed=31, clutter=0.72, bit_noise=0.05)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(7))]
+    frames[3] = tuple(a[:350] for a in frames[3])          # a sparse frame: its pairs behave differently
+    n_iter = 1100
+    counts = TrackingFrontend(cam, n_iter_max=1).run(frames).to_host()["st_count"]
+    rng = np.random.default_rng(77)
+    samples = np.zeros((6, n_iter, 4), np.int32)
+    for p in range(6):
+        samples[p] = np.stack([rng.choice(int(counts[p]), 4, replace=False) for _ in range(n_iter)])
+    res = TrackingFrontend(cam, n_iter_max=n_iter).run(frames, samples=samples)
+    iters = []
+    for p in range(6):
+        got = res.pair(p)
+        a, b = res.frame(p), res.frame(p + 1)
+        X = a["xyz"][got["query_idx"]]
+        pL, pR = b["pix_left"][got["train_idx"]], b["pix_right"][got["train_idx"]]
+        Rts, valid = kernels.p3p_solve_indexed(X, pL, samples[p], cam.K)
+        c = kernels.ransac_score(X, pL, pR, Rts, valid, cam.K, cam.M_right, 4.0)
+        rep = kernels.ransac_replay(c, len(X), 0.99999, n_iter).cpu().numpy()
+        assert (got["best_index"], got["best_count"], got["iterations"], got["n_iter_required"]) == \
+               (rep[0], rep[1], rep[2], rep[3]), (p, rep[:4])
+        np.testing.assert_array_equal(got["Rt_ransac"], Rts.cpu().numpy()[rep[0]])
+        mask = kernels.ransac_mask(X, pL, pR, got["Rt_ransac"], cam.K, cam.M_right, 4.0).cpu().numpy()
+        np.testing.assert_array_equal(got["mask"], mask.astype(bool))
+        iters.append(int(got["iterations"]))
+    # the case must actually reach the late rounds and stop in different ones
+    assert max(iters) > 768 and min(iters) < max(iters), iters
