@@ -186,31 +186,88 @@ __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
 constexpr int kHypPerRound = kBlock;
 constexpr int kPairGroup = 4096;   // pairs per group of launches (bounds the pose table)
 
-// Replays hypotheses [round*kHypPerRound, ...) of one pair; returns the lane of
-// a new best hypothesis of this round or -1.
+// Iterations required once the best hypothesis has `count` of n inliers
+// (pnp.py:150-156): ceil(log(1-p) / log(1 - w^4)), clamped to int.
+__device__ __forceinline__ int iterations_required(int count, int n, double log1mp) {
+  const double w = (double)count / (double)n;
+  const double w2 = w * w;
+  const double den = log(1.0 - w2 * w2);   // -inf when every point is an inlier
+  const double r = ceil(log1mp / den);
+  return r > 2147483647.0 ? 2147483647 : (int)r;
+}
+
+// Inclusive scan over the kBlock threads of the workgroup (max if kMax else
+// min); wave shuffles, then the four wave totals through LDS.  `wt` holds
+// kBlock / 64 ints.  Also returns the exclusive value (identity for thread 0).
+template <bool kMax>
+__device__ __forceinline__ int block_scan(int v, int identity, int *wt, int &exclusive) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off) v = kMax ? max(v, t) : min(v, t);
+  }
+  int ex = __shfl_up(v, 1, 64);
+  if (lane == 0) ex = identity;
+  if (lane == 63) wt[wave] = v;
+  __syncthreads();
+  int before = identity;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w)
+    if (w < wave) before = kMax ? max(before, wt[w]) : min(before, wt[w]);
+  __syncthreads();
+  exclusive = kMax ? max(ex, before) : min(ex, before);
+  return kMax ? max(v, before) : min(v, before);
+}
+
+// The sequential stopping rule of pnp.py:123-158 over hypotheses
+// [round*kHypPerRound, +kHypPerRound) of one pair, evaluated by the whole
+// workgroup (thread i looks at hypothesis i) with the same outcome as the
+// one-at-a-time loop:
+//   a hypothesis is a record if its count exceeds every earlier count and the
+//   best so far; the requirement in force when hypothesis i is reached is the
+//   minimum of the carried one and those of the earlier records; the loop
+//   reaches i iff i lies below that requirement and below the cap.  The
+//   requirement never grows, so the hypotheses reached form a prefix.
+// Updates the pair's state record and returns the lane of a new best
+// hypothesis of this round or -1 (same value in every thread).
+// `red` holds 4 + kBlock / 64 ints of LDS.
 __device__ int replay_round(int32_t *__restrict__ s, const int32_t *__restrict__ counts, int round,
-                            int n, int n_iter_max, double log1mp) {
-  int best_idx = s[0], best_count = s[1], iter_done = s[2], n_req = s[3];
-  int winner = -1;
-  while (iter_done < n_req && iter_done < n_iter_max && iter_done < (round + 1) * kHypPerRound) {
-    const int cc = counts[iter_done - round * kHypPerRound];
-    const int idx = iter_done;
-    ++iter_done;
-    if (cc < 0) continue;            // no pose from this sample: the reference skips it
-    if (cc > best_count) {
-      best_count = cc;
-      best_idx = idx;
-      winner = idx - round * kHypPerRound;
-      const double w = (double)best_count / (double)n;
-      const double w2 = w * w;
-      const double den = log(1.0 - w2 * w2);
-      if (best_count >= n) s[4] = 1;  // log(0): the reference raises here
-      const double r = ceil(log1mp / den);
-      n_req = r > 2147483647.0 ? 2147483647 : (int)r;
+                            int n, int n_iter_max, double log1mp, int *red) {
+  const int i = (int)threadIdx.x;
+  const int best0 = s[1], done0 = s[2], req0 = s[3];
+  const int g = round * kHypPerRound + i;
+  const int c = counts[i];                 // -1: no pose from this sample, -2: not generated
+  if (i < 4) red[i] = (i == 1) ? -1 : (i == 2 ? 2147483647 : 0);  // reached, winner, requirement, domain
+  int before;
+  block_scan<true>(max(c, best0), best0, red + 4, before);
+  const bool record = c > before;
+  const int req_i = record ? iterations_required(c, n, log1mp) : 2147483647;
+  int in_force;
+  block_scan<false>(min(req_i, req0), req0, red + 4, in_force);
+  const bool reached = g < in_force && g < n_iter_max;
+  if (reached) {
+    atomicAdd(&red[0], 1);
+    if (record) {
+      atomicMax(&red[1], i);
+      atomicMin(&red[2], req_i);
+      if (c >= n) red[3] = 1;              // log(0): the reference raises here
     }
   }
-  s[0] = best_idx; s[1] = best_count; s[2] = iter_done; s[3] = n_req;
-  s[7] = (iter_done < n_req && iter_done < n_iter_max) ? 0 : 1;
+  __syncthreads();
+  // the requirement reported is that of the latest record (the smallest of this round's,
+  // as it falls with the count); it may exceed the cap, which bounds the loop separately
+  const int n_reached = red[0], winner = red[1], req = red[1] >= 0 ? red[2] : req0, domain = red[3];
+  const int best_count = winner >= 0 ? counts[winner] : best0;
+  __syncthreads();                         // red[] is reused by the caller
+  if (i == 0) {
+    const int done = done0 + n_reached;
+    if (winner >= 0) { s[0] = round * kHypPerRound + winner; s[1] = best_count; }
+    s[2] = done;
+    s[3] = req;
+    if (domain) s[4] = 1;
+    s[7] = (done < req && done < n_iter_max) ? 0 : 1;
+  }
   return winner;
 }
 
@@ -231,18 +288,21 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
     int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info) {
   __shared__ int sh[3];  // stopped, winner lane of the replayed round, iterations required
+  __shared__ int red[4 + kBlock / 64];
   const int p = blockIdx.x;
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
-  if (threadIdx.x == 0) {
-    int winner = -1;
-    if (round == 0) {
+  int winner = -1;
+  if (round == 0) {
+    if (threadIdx.x == 0) {
       s[0] = -1; s[1] = 0; s[2] = 0; s[3] = prm.n_iter_max; s[4] = 0; s[5] = n; s[6] = 0;
       s[7] = (n >= 4 && n >= prm.min_points) ? 0 : 1;
-    } else if (!s[7]) {
-      winner = replay_round(s, counts + (size_t)p * kHypPerRound, round - 1, n, prm.n_iter_max,
-                            log(1.0 - prm.p_success));
     }
+  } else if (!s[7]) {      // same value in every thread: written by an earlier launch
+    winner = replay_round(s, counts + (size_t)p * kHypPerRound, round - 1, n, prm.n_iter_max,
+                          log(1.0 - prm.p_success), red);
+  }
+  if (threadIdx.x == 0) {
     sh[0] = s[7];
     sh[1] = winner;
     sh[2] = s[3];
@@ -376,11 +436,12 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
   const int p = blockIdx.x;
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
+  __shared__ int red[4 + kBlock / 64];
+  int winner = -1;
+  if (!s[7])               // same value in every thread: written by an earlier launch
+    winner = replay_round(s, counts + (size_t)p * kHypPerRound, rounds - 1, n, prm.n_iter_max,
+                          log(1.0 - prm.p_success), red);
   if (threadIdx.x == 0) {
-    int winner = -1;
-    if (!s[7])
-      winner = replay_round(s, counts + (size_t)p * kHypPerRound, rounds - 1, n, prm.n_iter_max,
-                            log(1.0 - prm.p_success));
     sh[0] = winner;
     sh[1] = s[0] >= 0;
     sh[2] = 0;
@@ -444,7 +505,8 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np), dim3(kBlock), 0, st, r, obase + g0,
                          tm_count + g0, cx, cpl, samples, prm, rt, counts,
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0);
-      const int per_span = r < kWideRounds ? 1 : chunks;
+      // narrow only where that still leaves at least a thousand wavefronts of work
+      const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
       hipLaunchKernelGGL(ransac_count_kernel,
                          dim3(slamhip_ceil_div(chunks, per_span), kHypPerRound / 64, np), dim3(64), 0,
                          st, obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,

@@ -8,6 +8,8 @@ from slam_amd.utils.synth import StereoSequence
 
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 nfeat = int(sys.argv[2]) if len(sys.argv) > 2 else 1500
+if len(sys.argv) > 3:                      # feature count per image drawn from [nfeat, argv[3]]
+    nfeat = (nfeat, int(sys.argv[3]))
 cam = CameraModel.kitti_like()
 seq = StereoSequence(cam, n_frames=F, n_features=nfeat, seed=100, clutter=0.6)
 frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(F))]
