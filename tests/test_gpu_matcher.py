@@ -164,3 +164,42 @@ def test_facade_errors_like_reference():
     from slam_amd import DescriptorMatcher
     with pytest.raises(ValueError):
         DescriptorMatcher(cross_check=False, matcher_type="flann")
+
+
+@pytest.mark.parametrize("desc_bytes,stride,offset", [(61, 61, 0), (61, 61, 1), (61, 67, 3), (32, 32, 2),
+                                                      (64, 64, 1), (64, 70, 0), (1, 1, 0), (5, 9, 3),
+                                                      (128, 128, 3), (100, 101, 2)])
+def test_rows_at_any_alignment_and_stride(desc_bytes, stride, offset):
+    """Through the C ABI with rows at an arbitrary byte offset and stride (the row
+    packer fetches aligned dwords and funnel-shifts): results equal the oracle.
+    The buffers end exactly at the last row's last byte."""
+    import ctypes as C
+    from slam_amd import _lib, kernels
+    rng = np.random.default_rng(desc_bytes * 1000 + stride * 10 + offset)
+    nq, nt = 333, 517
+    q = rng.integers(0, 256, (nq, desc_bytes), dtype=np.uint8)
+    t = rng.integers(0, 256, (nt, desc_bytes), dtype=np.uint8)
+    t[100] = t[7]; t[300] = t[7]; q[5] = t[7]                      # ties
+    ref_i, ref_d = so.hamming_knn2(q, t)
+
+    def strided(a):
+        n = len(a)
+        buf = rng.integers(0, 256, offset + (n - 1) * stride + desc_bytes, dtype=np.uint8)
+        for r in range(n):
+            buf[offset + r * stride: offset + r * stride + desc_bytes] = a[r]
+        return torch.from_numpy(buf).cuda()
+
+    dq, dt = strided(q), strided(t)
+    idx2 = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    dist2 = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    need = _lib.lib.slamhip_hamming_knn2_workspace_bytes(nq, nt, 1, nq, nt, desc_bytes)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    idx2.fill_(-7); dist2.fill_(-7)
+    rc = _lib.lib.slamhip_hamming_knn2(C.c_void_p(dq.data_ptr() + offset), nq,
+                                       C.c_void_p(dt.data_ptr() + offset), nt, desc_bytes, stride,
+                                       C.c_void_p(idx2.data_ptr()), C.c_void_p(dist2.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), C.c_size_t(need),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    np.testing.assert_array_equal(idx2.cpu().numpy(), ref_i)
+    np.testing.assert_array_equal(dist2.cpu().numpy(), ref_d)
