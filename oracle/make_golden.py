@@ -88,9 +88,88 @@ def scene(rng, cam, n, sigma=0.5, outliers=0.3):
     return X, uvl.astype(np.float32), uvr.astype(np.float32)
 
 
+def tracking_records(rng, n_frames=7):
+    """Synthetic per-frame / per-pair records of the shape the front-end hands over,
+    with several previous rows matched to the same current row (better and worse
+    distances in both orders), equal distances, masked-out matches and rows that
+    never join a track."""
+    frames, pairs = [], []
+    for f in range(n_frames):
+        m = int(rng.integers(25, 60))
+        frames.append({"pix_left": rng.uniform(0, 1200, (m, 2)).astype(np.float32),
+                       "pix_right": rng.uniform(0, 1200, (m, 2)).astype(np.float32),
+                       "inlier_des_left": rng.integers(0, 256, (m, 61), dtype=np.uint8)})
+    for p in range(n_frames - 1):
+        n, mt = len(frames[p]["pix_left"]), len(frames[p + 1]["pix_left"])
+        train = rng.integers(0, mt, n).astype(np.int32)
+        train[: n // 3] = rng.integers(0, max(mt // 6, 1), n // 3)      # many collisions on few rows
+        dist = rng.integers(0, 40, n).astype(np.int32)                 # small range: equal distances
+        order = np.argsort(dist, kind="stable")                        # matches arrive sorted by distance
+        pairs.append({"query_idx": order.astype(np.int32), "train_idx": train[order], "dist": dist[order],
+                      "mask": rng.random(n) < 0.7, "Rt": rng.normal(size=(3, 4))})
+    # one pair with the collisions arriving worst-first as well (not sorted)
+    rev = np.argsort(-pairs[2]["dist"], kind="stable")
+    for k in ("query_idx", "train_idx", "dist", "mask"):
+        pairs[2][k] = pairs[2][k][rev]
+    return frames, pairs
+
+
+class _Records:
+    """The accessors db_adapter.replay_into_db uses, over plain lists."""
+    def __init__(self, frames, pairs):
+        self._f, self._p, self.n_frames = frames, pairs, len(frames)
+
+    def frame(self, f):
+        return self._f[f]
+
+    def pair(self, p):
+        return self._p[p]
+
+
+def make_tracking_db_fixture():
+    """(A6) state of the reference's own TrackingDB after the hand-over adapter has
+    replayed synthetic records into it with the reference's own Link class."""
+    from slam.backend.tracking.database import TrackingDB, Link  # type: ignore
+    from slam_amd.backend.tracking import db_adapter
+    rng = np.random.default_rng(424242)
+    frames, pairs = tracking_records(rng)
+    db = db_adapter.replay_into_db(TrackingDB(), _Records(frames, pairs), link_factory=Link)
+    db._check_consistency()
+    out = {}
+    frames_sorted = sorted(db.frameId_to_trackIds_list)
+    out["track_ids"] = np.concatenate([np.asarray(db.frameId_to_trackIds_list[f], np.int64) for f in frames_sorted])
+    out["track_ids_off"] = np.concatenate([[0], np.cumsum([len(db.frameId_to_trackIds_list[f])
+                                                           for f in frames_sorted])]).astype(np.int64)
+    out["last_track"], out["last_frame"] = np.int64(db.last_trackId), np.int64(db.last_frameId)
+    keys = sorted(db.linkId_to_link)
+    out["link_keys"] = np.asarray(keys, np.int64).reshape(-1, 2)
+    out["link_xyz"] = np.asarray([[db.linkId_to_link[k].x_left, db.linkId_to_link[k].x_right,
+                                   db.linkId_to_link[k].y] for k in keys], np.float64).reshape(-1, 3)
+    tk = sorted(db.trackId_to_frames)
+    out["track_keys"] = np.asarray(tk, np.int64)
+    out["track_len"] = np.asarray([len(db.trackId_to_frames[t]) for t in tk], np.int64)
+    out["leftover_count"] = np.asarray([len(db.leftover_links.get(f, [])) for f in frames_sorted], np.int64)
+    # all_frame_links(f) of an inner frame: every feature's link, track member or not (database.py:199-218)
+    afl = db.all_frame_links(2)
+    out["all_links_frame2"] = np.asarray([[l.x_left, l.x_right, l.y] for l in afl], np.float64)
+    # inputs
+    out["n_frames"] = np.int64(len(frames))
+    out["frame_off"] = np.concatenate([[0], np.cumsum([len(f["pix_left"]) for f in frames])]).astype(np.int64)
+    out["pair_off"] = np.concatenate([[0], np.cumsum([len(p["mask"]) for p in pairs])]).astype(np.int64)
+    for k in ("pix_left", "pix_right", "inlier_des_left"):
+        out[k] = np.concatenate([f[k] for f in frames])
+    for k in ("query_idx", "train_idx", "dist", "mask"):
+        out[k] = np.concatenate([p[k] for p in pairs])
+    out["Rt"] = np.stack([p["Rt"] for p in pairs])
+    np.savez_compressed(os.path.join(OUT, "ref_tracking_db.npz"), **out)
+    print("ref_tracking_db.npz:", int(out["last_track"]) + 1, "tracks issued,", len(keys), "links,",
+          len(tk), "tracks alive")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     PnP, Triangulation, CameraModel, gu = import_reference()
+    make_tracking_db_fixture()
 
     calib = os.path.join(tempfile.mkdtemp(), "calib.txt")
     with open(calib, "w") as fh:

@@ -92,3 +92,42 @@ def test_saved_records_replay_like_the_live_result(tmp_path):
                    [(m.queryIdx, m.trainIdx, m.distance) for m in mb]
             np.testing.assert_array_equal(ia, ib)
     np.testing.assert_array_equal(back.relative_Rts(), seq.relative_Rts)
+
+
+class _FixtureRecords:
+    """Records stored in ref_tracking_db.npz, with the accessors replay_into_db uses."""
+
+    def __init__(self, g):
+        self.g, self.n_frames = g, int(g["n_frames"])
+
+    def frame(self, f):
+        lo, hi = int(self.g["frame_off"][f]), int(self.g["frame_off"][f + 1])
+        return {k: self.g[k][lo:hi] for k in ("pix_left", "pix_right", "inlier_des_left")}
+
+    def pair(self, p):
+        lo, hi = int(self.g["pair_off"][p]), int(self.g["pair_off"][p + 1])
+        d = {k: self.g[k][lo:hi] for k in ("query_idx", "train_idx", "dist", "mask")}
+        d["Rt"] = self.g["Rt"][p]
+        return d
+
+
+def test_replay_reproduces_the_reference_tracking_db_state(golden):
+    """ref_tracking_db.npz holds the state of the reference's own TrackingDB after
+    db_adapter.replay_into_db fed it these records (several previous rows matched
+    to one current row in better-first and worse-first order, equal distances,
+    masked matches).  Replaying the same records here through the same adapter into
+    the restatement of add_frame must give that state: track ids per feature row,
+    ids issued, every (frame, track) link with its coordinates, track lengths,
+    leftover counts and all_frame_links of an inner frame."""
+    from oracle.tracking_db_oracle import TrackDBOracle
+    g = golden("ref_tracking_db.npz")
+    db = db_adapter.replay_into_db(TrackDBOracle(), _FixtureRecords(g))
+    s = db.summary()
+    for k in ("track_ids", "track_ids_off", "last_track", "last_frame", "link_keys", "track_keys",
+              "track_len", "leftover_count"):
+        np.testing.assert_array_equal(s[k], g[k], err_msg=k)
+    np.testing.assert_array_equal(s["link_xyz"], g["link_xyz"])          # float32 pixels widened: exact
+    np.testing.assert_array_equal(db.all_frame_links(2), g["all_links_frame2"])
+    assert int(g["last_track"]) + 1 > len(g["track_keys"])               # some tracks were replaced
+    # every surviving track spans at least two frames (database.py:507)
+    assert (s["track_len"] >= 2).all()

@@ -241,3 +241,26 @@ def test_ransac_rounds_equal_stand_alone_kernels():
         iters.append(int(got["iterations"]))
     # the case must actually reach the late rounds and stop in different ones
     assert max(iters) > 768 and min(iters) < max(iters), iters
+
+
+def test_frontend_result_builds_a_consistent_track_db():
+    """The batched result, replayed through the hand-over adapter into the
+    restatement of the reference's TrackingDB.add_frame (pinned to the reference's
+    own DB by tests/golden/ref_tracking_db.npz): every invariant add_frame asserts
+    holds, and the tracks it builds follow real landmarks across frames."""
+    from oracle.tracking_db_oracle import TrackDBOracle
+    from slam_amd.backend.tracking import db_adapter
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam, seq, frames = _sequence(6, 600, seed=17)
+    res = TrackingFrontend(cam, seed=2).run(frames)
+    db = db_adapter.replay_into_db(TrackDBOracle(), res)
+    s = db.summary()
+    assert int(s["last_frame"]) == 5
+    assert (s["track_len"] >= 2).all() and s["track_len"].sum() == len(s["link_keys"])
+    assert len(s["track_keys"]) > 200 and s["track_len"].max() == 6      # landmarks seen in all six frames
+    # links of a frame: one per RANSAC-inlier match into or out of it
+    for f in range(6):
+        n_on_f = int((s["link_keys"][:, 0] == f).sum())
+        ids = np.asarray(db.track_ids[f])
+        assert n_on_f == int((ids >= 0).sum()) == len(set(ids[ids >= 0].tolist()))
+        assert len(db.all_frame_links(f)) == len(res.frame(f)["left_idx"])
