@@ -166,6 +166,58 @@ def make_tracking_db_fixture():
           len(tk), "tracks alive")
 
 
+class _MD:
+    def __init__(self, q, t, d=0.0):
+        self.queryIdx, self.trainIdx, self.distance = int(q), int(t), float(d)
+
+
+def make_plumbing_fixture(PnP, cam):
+    """(A7) index plumbing either side of the kernels, from the reference's own
+    functions: DescriptorMatcher.extract_matched_pixels (descriptor_matcher.py:44-52),
+    PnP.create_L_R_pixels (pnp.py:53-83, both pair_0_or_1 values) and
+    TrackingDB.create_links (database.py:256-285, both orderings, with and without
+    an inlier list)."""
+    from slam.frontend.vision.descriptor_matcher import DescriptorMatcher  # type: ignore
+    from slam.backend.tracking.database import TrackingDB  # type: ignore
+    rng = np.random.default_rng(777)
+    nL, nR = 90, 80
+    kl = rng.uniform(0, 1226, (nL, 2)).astype(np.float32)
+    kr = rng.uniform(0, 1226, (nR, 2)).astype(np.float32)
+    kpsL = [_KP(*p) for p in kl]
+    kpsR = [_KP(*p) for p in kr]
+    des = rng.integers(0, 256, (nL, 61), dtype=np.uint8)
+    # stereo matches: one per left row in shuffled order (as after the sort by distance)
+    q = rng.permutation(nL)
+    t = rng.integers(0, nR, nL)
+    intra = [_MD(a, b, d) for a, b, d in zip(q, t, rng.integers(0, 99, nL))]
+    keep = rng.random(nL) < 0.6
+    inlier_matches = [m for m, k in zip(intra, keep) if k]
+    inlier_idx = [m.queryIdx for m in inlier_matches]                    # fill_database.py:171 order
+    pl, pr = DescriptorMatcher.extract_matched_pixels(kpsL, kpsR, inlier_matches)
+    # temporal matches between two inlier lists of lengths n0 (this frame as frame 0) and n1
+    n0 = len(inlier_idx)
+    m01_as0 = [_MD(a, b) for a, b in zip(rng.permutation(n0), rng.integers(0, 50, n0))]
+    m01_as1 = [_MD(a, b) for a, b in zip(rng.permutation(40), rng.integers(0, n0, 40))]
+    pnp = PnP(cam, 4.0)
+    pL0, pR0 = pnp.create_L_R_pixels(m01_as0, intra, inlier_idx, kpsL, kpsR, 0)
+    pL1, pR1 = pnp.create_L_R_pixels(m01_as1, intra, inlier_idx, kpsL, kpsR, 1)
+    f_ord, links_ord = TrackingDB.create_links(des, kpsL, kpsR, inlier_matches, inliers=None, keep_match_order=True)
+    mask = (rng.random(len(intra)) < 0.5).tolist()
+    f_msk, links_msk = TrackingDB.create_links(des, kpsL, kpsR, intra, inliers=mask, keep_match_order=True)
+    f_row, links_row = TrackingDB.create_links(des, kpsL, kpsR, intra, inliers=mask, keep_match_order=False)
+    xyz = lambda ls: np.asarray([[l.x_left, l.x_right, l.y] for l in ls], np.float64).reshape(-1, 3)
+    np.savez_compressed(
+        os.path.join(OUT, "ref_plumbing.npz"), kp_left=kl, kp_right=kr, des=des,
+        intra_q=np.array([m.queryIdx for m in intra]), intra_t=np.array([m.trainIdx for m in intra]),
+        keep=keep, mask=np.array(mask), extract_L=pl, extract_R=pr,
+        m0_q=np.array([m.queryIdx for m in m01_as0]), m0_t=np.array([m.trainIdx for m in m01_as0]),
+        m1_q=np.array([m.queryIdx for m in m01_as1]), m1_t=np.array([m.trainIdx for m in m01_as1]),
+        pix_L0=pL0, pix_R0=pR0, pix_L1=pL1, pix_R1=pR1,
+        links_ord=xyz(links_ord), feat_ord=f_ord, links_msk=xyz(links_msk), feat_msk=f_msk,
+        links_row=xyz(links_row), feat_row=f_row)
+    print("ref_plumbing.npz:", len(inlier_matches), "stereo inliers")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     PnP, Triangulation, CameraModel, gu = import_reference()
@@ -176,6 +228,7 @@ def main():
         fh.write("P0: " + " ".join(repr(v) for v in KITTI_P0) + "\n")
         fh.write("P1: " + " ".join(repr(v) for v in KITTI_P1) + "\n")
     cam = CameraModel.from_kitti(calib)
+    make_plumbing_fixture(PnP, cam)
     rng = np.random.default_rng(20240511)
 
     # ---- (A1) camera model
