@@ -218,6 +218,71 @@ def make_plumbing_fixture(PnP, cam):
     print("ref_plumbing.npz:", len(inlier_matches), "stereo inliers")
 
 
+def make_ransac_loop_fixture(PnP, cam):
+    """(A8) the reference's own PnP.ransac_pnp_pair1 loop (pnp.py:102-160), run as it
+    is, with only its minimal solver replaced: solve_pnp (a thin cv2.solvePnP wrapper,
+    pnp.py:36-43; cv2 is absent) returns the i-th pose of a prepared list on its i-th
+    call, None where the list says the solve failed.  Everything after the solve --
+    projections, errors, supporters, the adaptive stopping rule, early_inliers, the
+    math.log(0) of an all-inlier hypothesis -- is the reference's code.  Recorded per
+    case: the returned mask (or the exception) and the number of solve_pnp calls."""
+    from slam_amd.utils.synth import perturbed_hypotheses
+    Rt_true = np.hstack([np.eye(3), np.zeros((3, 1))])
+    cases = [
+        dict(name="typical", seed=1, n=240, h=900, good=0.02, outliers=0.45, kw={}),
+        dict(name="early", seed=2, n=200, h=600, good=0.05, outliers=0.3, kw={"early_inliers": 90}),
+        dict(name="cap", seed=3, n=180, h=700, good=0.0, outliers=0.5, kw={"n_iter_max": 333}),
+        dict(name="failures", seed=4, n=150, h=500, good=0.03, outliers=0.4, kw={}, fail=0.35),
+        dict(name="loose_p", seed=5, n=220, h=400, good=0.1, outliers=0.3, kw={"p_success": 0.9}),
+        dict(name="all_inliers", seed=6, n=60, h=50, good=1.0, outliers=0.0, kw={}, exact=True),
+        dict(name="no_inlier_ever", seed=7, n=80, h=40, good=0.0, outliers=1.0, kw={"n_iter_max": 40}, far=True),
+    ]
+    out = {"names": np.array([c["name"] for c in cases])}
+    for c in cases:
+        rng = np.random.default_rng(c["seed"])
+        X, uvl, uvr = scene(rng, cam, c["n"], sigma=0.0 if c.get("exact") else 0.5, outliers=c["outliers"])
+        X = X.astype(np.float32)
+        if c.get("far"):
+            uvl = uvl + 500.0
+        Rts, valid = perturbed_hypotheses(rng, Rt_true, c["h"], good_fraction=c["good"])
+        if c.get("exact"):
+            Rts[:] = Rt_true
+            # the scene was projected from float64 points; re-project the float32 ones exactly
+            Xh = np.column_stack([X.astype(np.float64), np.ones(len(X))])
+            pl, pr = Xh @ cam.P_left.T, Xh @ cam.P_right.T
+            uvl = (pl[:, :2] / pl[:, 2:3]).astype(np.float32)
+            uvr = (pr[:, :2] / pr[:, 2:3]).astype(np.float32)
+        if "fail" in c:
+            valid = (rng.random(c["h"]) > c["fail"]).astype(np.uint8)
+        pnp = PnP(cam, 2.0)
+        calls = [0]
+
+        def fake_solve(obj4, img4, flag, Rts=Rts, valid=valid, calls=calls):
+            i = calls[0]
+            calls[0] += 1
+            return Rts[i].copy() if valid[i] else None
+        pnp.solve_pnp = fake_solve
+        raised = ""
+        try:
+            mask = pnp.ransac_pnp_pair1(X, uvl, uvr, **c["kw"])
+        except ValueError as e:                      # math domain error, pnp.py:150-153
+            mask, raised = None, str(e)
+        k = c["name"]
+        out[k + "_X"], out[k + "_mL"], out[k + "_mR"] = X, uvl, uvr
+        keep = min(len(Rts), calls[0] + 5)            # the loop never looked past its last call
+        out[k + "_Rts"], out[k + "_valid"] = Rts[:keep], valid[:keep]
+        out[k + "_mask"] = np.zeros(0, bool) if mask is None else np.asarray(mask, bool)
+        out[k + "_has_mask"] = np.bool_(mask is not None)
+        out[k + "_raised"] = np.array(raised)
+        out[k + "_calls"] = np.int64(calls[0])
+        out[k + "_kw"] = np.array([c["kw"].get("p_success", 0.99999), c["kw"].get("n_iter_max", 2500),
+                                   c["kw"].get("early_inliers", -1)], np.float64)
+        print(" ", k, "calls", calls[0], "inliers", None if mask is None else int(mask.sum()), raised)
+    out["pixel_thresh"] = np.float64(2.0)
+    out["K"], out["M_right"] = cam.K, cam.M_right
+    np.savez_compressed(os.path.join(OUT, "ref_ransac_loop.npz"), **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     PnP, Triangulation, CameraModel, gu = import_reference()
@@ -229,6 +294,7 @@ def main():
         fh.write("P1: " + " ".join(repr(v) for v in KITTI_P1) + "\n")
     cam = CameraModel.from_kitti(calib)
     make_plumbing_fixture(PnP, cam)
+    make_ransac_loop_fixture(PnP, cam)
     rng = np.random.default_rng(20240511)
 
     # ---- (A1) camera model

@@ -191,3 +191,40 @@ def test_packed_fp32_screening_never_changes_a_count():
     eL, eR = so.hypothesis_errors(cam.K, cam.M_right, Rts[0], X, mL, mR)
     sure = (np.abs(eL - thr) > BAND) & (np.abs(eR - thr) > BAND)
     assert abs(int(((eL <= thr) & (eR <= thr))[sure].sum()) - int(ref[0])) <= int((~sure).sum())
+
+
+def test_facade_loop_equals_reference_loop(golden):
+    """ref_ransac_loop.npz is the reference's own ransac_pnp_pair1 loop fed a
+    prepared pose list through its solve_pnp.  The façade fed the same list returns
+    the same mask (None / ValueError in the same cases), and the device replay
+    stops after the same number of iterations."""
+    from slam_amd import kernels, CameraModel, PnP
+    g = golden("ref_ransac_loop.npz")
+    cam = CameraModel.kitti_like()
+    np.testing.assert_array_equal(cam.K, g["K"])
+    thr = float(g["pixel_thresh"])
+    for name in g["names"]:
+        k = str(name)
+        X, mL, mR = g[k + "_X"], g[k + "_mL"], g[k + "_mR"]
+        Rts, valid = g[k + "_Rts"], g[k + "_valid"]
+        p_success, n_iter_max, early = g[k + "_kw"]
+        early = None if early < 0 else int(early)
+        pnp = PnP(cam, thr)
+        raised = str(g[k + "_raised"])
+        if raised:
+            with pytest.raises(ValueError, match=raised):
+                pnp.ransac_pnp_pair1(X, mL, mR, float(p_success), int(n_iter_max), early,
+                                     hypotheses=(Rts, valid))
+            continue
+        for block in (256, 7):       # the replay carries its state across scoring blocks of any size
+            mask = pnp.ransac_pnp_pair1(X, mL, mR, float(p_success), int(n_iter_max), early,
+                                        hypotheses=(Rts, valid), block=block)
+            if not bool(g[k + "_has_mask"]):
+                assert mask is None, k
+            else:
+                assert mask.dtype == bool
+                np.testing.assert_array_equal(mask, g[k + "_mask"], err_msg=f"{k} block {block}")
+        counts = kernels.ransac_score(X, mL, mR, Rts, valid, cam.K, cam.M_right, thr)
+        rep = kernels.ransac_replay(counts, len(X), float(p_success), int(n_iter_max), early).cpu().numpy()
+        assert rep[2] == int(g[k + "_calls"]), (k, rep)
+        assert rep[1] == int(g[k + "_mask"].sum())

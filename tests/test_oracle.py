@@ -110,3 +110,32 @@ def test_ransac_replay_golden(golden):
 def test_ransac_replay_domain_error_like_reference():
     with pytest.raises(ValueError):
         so.ransac_replay([10, 50], 50)  # all points inliers -> math.log(0)
+
+
+def test_ransac_loop_matches_reference_loop(golden):
+    """ref_ransac_loop.npz: the reference's own ransac_pnp_pair1 loop run with its
+    solve_pnp replaced by a prepared pose list.  The oracle's scoring + replay of
+    the same list must give the same mask, the same number of iterations, and
+    raise where the reference raised."""
+    g = golden("ref_ransac_loop.npz")
+    K, MR, thr = g["K"], g["M_right"], float(g["pixel_thresh"])
+    for name in g["names"]:
+        k = str(name)
+        X, mL, mR = g[k + "_X"], g[k + "_mL"], g[k + "_mR"]
+        Rts, valid = g[k + "_Rts"], g[k + "_valid"]
+        p_success, n_iter_max, early = g[k + "_kw"]
+        early = None if early < 0 else int(early)
+        counts = so.score_hypotheses(K, MR, Rts, valid, X, mL, mR, thr)
+        raised = str(g[k + "_raised"])
+        if raised:
+            with pytest.raises(ValueError, match=raised):
+                so.ransac_replay(counts, len(X), float(p_success), int(n_iter_max), early)
+            continue
+        best, best_count, iters, _ = so.ransac_replay(counts, len(X), float(p_success), int(n_iter_max), early)
+        assert iters == int(g[k + "_calls"]), k
+        if not bool(g[k + "_has_mask"]):
+            assert best == -1
+            continue
+        mask = so.hypothesis_mask(K, MR, Rts[best], X, mL, mR, thr)
+        np.testing.assert_array_equal(mask, g[k + "_mask"], err_msg=k)
+        assert best_count == int(g[k + "_mask"].sum())
