@@ -244,7 +244,7 @@ def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
         keyframes.append((fr["links"], fr["inlier_des_left"]))
     pairs = np.array([(i, n) for n in range(KF) for i in range(n)], dtype=np.int64)[rank::world]
     ver = PairVerifier(cam, seed=rank).set_keyframes(keyframes)
-    ver.verify(pairs)                                           # warm-up: sizes the workspace
+    ver.verify(pairs).verified_matches()                        # warm-up: sizes the workspace
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

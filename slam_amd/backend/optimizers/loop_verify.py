@@ -67,17 +67,14 @@ class VerifyResult(dict):
         off = np.concatenate([[0], np.cumsum(count)]).astype(np.int64)
         out = {"pairs": idx, "off": off}
         dev = self._dev["tm_query"].device
-        if len(idx):
-            seg = torch.repeat_interleave(torch.arange(len(idx), device=dev),
-                                          torch.from_numpy(count).to(dev))
-            rows = (torch.from_numpy(start).to(dev)[seg] +
-                    (torch.arange(int(off[-1]), device=dev) - torch.from_numpy(off[:-1]).to(dev)[seg]))
-        else:
-            rows = torch.zeros(0, dtype=torch.int64, device=dev)
+        # row list built on the host (verified pairs are few), one index_select per array
+        rows_h = (np.concatenate([np.arange(s0, s0 + c, dtype=np.int64) for s0, c in zip(start, count)])
+                  if len(idx) else np.zeros(0, np.int64))
+        rows = torch.from_numpy(rows_h).to(dev)
         for key, (name, cast) in self._LAZY.items():
             if key == "xyz":
                 continue
-            a = self._dev[name][rows].cpu().numpy()
+            a = self._dev[name].index_select(0, rows).cpu().numpy()
             out[key] = a.astype(cast) if cast is not None else a
         return out
 

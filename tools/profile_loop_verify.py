@@ -25,5 +25,14 @@ t0 = time.perf_counter()
 res = ver.verify(pairs)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
+t0 = time.perf_counter()
+vm = res.verified_matches()
+torch.cuda.synchronize()
+dt_vm = time.perf_counter() - t0
+t0 = time.perf_counter()
+res2 = ver.verify(pairs)
+torch.cuda.synchronize()
+dt2 = time.perf_counter() - t0
+print(f"verified_matches: {dt_vm*1e3:.1f} ms ({int(vm['off'][-1])} rows); second full verify: {dt2*1e3:.1f} ms")
 print(f"{len(pairs)} pairs of {KF} keyframes: {dt*1e3:.1f} ms, {len(pairs)/dt:.0f} pairs/s, "
       f"{int(res['ok'].sum())} verified, mean iterations {res['iterations'].mean():.0f}")
