@@ -51,7 +51,8 @@ const char *slamhip_strerror(int code);
 /* Diagnostics only (kernel-variant benchmarks): knob 0 = matcher kernel variant
  * (-1 auto), knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
  * screening in the consensus counting kernels (1 = on, the default; 0 = fp64 only;
- * the counts are identical either way).  Process-global; not for use while other
+ * the counts are identical either way), knob 3 = matcher block size (0 auto, 256 or
+ * 128 queries per block).  Process-global; not for use while other
  * threads are inside the library. */
 int slamhip_tune(int knob, int value);
 

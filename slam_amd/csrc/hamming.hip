@@ -83,8 +83,8 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
 // ---------------------------------------------------------------------------
 // Main kernel.
 // ---------------------------------------------------------------------------
-template <int W, int Q, bool USE_LDS>
-__global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
+template <int W, int Q, bool USE_LDS, int T = kThreads>
+__global__ __launch_bounds__(T) void hamming_top2_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
     const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
   // results of query row r of this pair go to output row o0 + r (default: the
   // query's own global row); nq_total is the number of output rows
   const int o0 = out_off ? out_off[pair] : q0;
-  const int qblk = blockIdx.x * (kThreads * Q);
+  const int qblk = blockIdx.x * (T * Q);
   if (qblk >= nq) return;  // block-uniform
 
   const int n_splits = gridDim.y;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
   int qrow[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
-    qrow[q] = qblk + q * kThreads + (int)threadIdx.x;
+    qrow[q] = qblk + q * T + (int)threadIdx.x;
     const int r = min(qrow[q], nq - 1);
     const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + r) * W);
 #pragma unroll
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kThreads) void hamming_top2_kernel(
       const int rows = min(kTileRows, r_end - tile_begin);
       __syncthreads();
       const uint4 *src = reinterpret_cast<const uint4 *>(tp + (size_t)(t0 + tile_begin) * W);
-      for (int i = threadIdx.x; i < rows * (W / 4); i += kThreads) tile[i] = src[i];
+      for (int i = threadIdx.x; i < rows * (W / 4); i += T) tile[i] = src[i];
       __syncthreads();
       // wave-uniform trip count kept in an SGPR so the loop control stays off the VALU
       const int rows_u = __builtin_amdgcn_readfirstlane(rows);
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void rank_sort_kernel(const int32_t *__restric
 }
 
 struct MatchPlan {
-  int W, Q, qblocks, splits;
+  int W, Q, qblocks, splits, threads;
   bool use_lds;
   size_t off_qp, off_tp, off_part, total;
 };
@@ -373,6 +373,7 @@ ProfEvents g_prof;
 
 int g_force_variant = -1;  // diagnostics: -1 auto, bit0 = LDS, bits 1.. = Q
 int g_force_splits = 0;
+int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
 
 MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                     int desc_bytes, long long n_out = -1, bool prepacked = false) {
@@ -388,7 +389,17 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
     p.use_lds = (g_force_variant & 1) != 0;
     p.Q = (g_force_variant >> 1) == 2 && p.W <= 16 ? 2 : 1;
   }
-  p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, kThreads * p.Q);
+  // Half-size blocks when that fills the last block of a pair much better (e.g. 610
+  // queries: 3 x 256 leaves 158 lanes idle, 5 x 128 leaves 30).  Default variant only.
+  p.threads = kThreads;
+  if (p.use_lds && p.Q == 1 && max_nq > 0) {
+    const int idle_full = slamhip_ceil_div(max_nq, kThreads) * kThreads - max_nq;
+    const int idle_half = slamhip_ceil_div(max_nq, kThreads / 2) * (kThreads / 2) - max_nq;
+    if (idle_full - idle_half >= kThreads / 2 && idle_full * 8 > max_nq) p.threads = kThreads / 2;
+  }
+  if (g_force_threads == kThreads || g_force_threads == kThreads / 2)
+    p.threads = (p.use_lds && p.Q == 1) ? g_force_threads : kThreads;
+  p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, p.threads * p.Q);
   const long long base_blocks = (long long)p.qblocks * (n_pairs > 0 ? n_pairs : 1);
   const long long target = 2048;  // 8 blocks of 4 waves per CU
   long long s = (target + base_blocks - 1) / base_blocks;
@@ -409,13 +420,13 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   return p;
 }
 
-template <int W, int Q, bool L>
+template <int W, int Q, bool L, int T = kThreads>
 void launch_top2(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp,
                  const int32_t *q_off, const int32_t *q_cnt, const int32_t *t_off,
                  const int32_t *t_cnt, const int32_t *out_off, int nq, int nt, int nq_total,
                  uint2 *part, int32_t *idx2, int32_t *dist2) {
-  hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L>), grid, dim3(kThreads), 0, st, qp, tp, q_off,
-                     q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2);
+  hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L, T>), grid, dim3(T), 0, st, qp, tp, q_off, q_cnt,
+                     t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2);
 }
 
 int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total,
@@ -473,7 +484,14 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 #define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
   launch_top2<WW, QQ, LL>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, d_out_off, nqs, nts, \
                           n_out_total, part, d_idx2, d_dist2)
-  if (p.W == 8) {
+#define SLAMHIP_DISPATCH_HALF(WW)                                                                  \
+  launch_top2<WW, 1, true, kThreads / 2>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt,     \
+                                         d_out_off, nqs, nts, n_out_total, part, d_idx2, d_dist2)
+  if (p.threads == kThreads / 2) {
+    if (p.W == 8) SLAMHIP_DISPATCH_HALF(8);
+    else if (p.W == 16) SLAMHIP_DISPATCH_HALF(16);
+    else SLAMHIP_DISPATCH_HALF(32);
+  } else if (p.W == 8) {
     if (p.Q == 2) { if (p.use_lds) SLAMHIP_DISPATCH(8, 2, true); else SLAMHIP_DISPATCH(8, 2, false); }
     else          { if (p.use_lds) SLAMHIP_DISPATCH(8, 1, true); else SLAMHIP_DISPATCH(8, 1, false); }
   } else if (p.W == 16) {
@@ -483,6 +501,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     if (p.use_lds) SLAMHIP_DISPATCH(32, 1, true); else SLAMHIP_DISPATCH(32, 1, false);
   }
 #undef SLAMHIP_DISPATCH
+#undef SLAMHIP_DISPATCH_HALF
   if (ev) (void)hipEventRecord(ev->second, st);
   SLAMHIP_CHECK_LAUNCH();
 
@@ -505,11 +524,13 @@ extern "C" {
 // Diagnostics knob used by the kernel-variant benchmark: knob 0 = kernel
 // variant (-1 auto; bit0 LDS-staged train tile, value>>1 = queries per lane),
 // knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
-// screening in the consensus counting kernels (1 on, 0 fp64 only; same counts).
+// screening in the consensus counting kernels (1 on, 0 fp64 only; same counts),
+// knob 3 = matcher block size (0 auto, 256, 128).
 int slamhip_tune(int knob, int value) {
   if (knob == 0) g_force_variant = value;
   else if (knob == 1) g_force_splits = value;
   else if (knob == 2) slamhip_internal::g_ransac_screen = value ? 1 : 0;
+  else if (knob == 3) g_force_threads = value;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
 }

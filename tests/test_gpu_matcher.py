@@ -57,6 +57,40 @@ def test_every_kernel_variant_with_ties(variant, splits):
         np.testing.assert_array_equal(dd, ed, err_msg=f"{nq}x{nt}x{d}")
 
 
+@pytest.mark.parametrize("threads", [128, 256])
+@pytest.mark.parametrize("splits", [0, 1, 5])
+def test_both_block_sizes_with_ties_and_ragged_batches(threads, splits):
+    """Matcher blocks of 256 and of 128 queries (tune knob 3; the plan picks 128 where
+    it fills a pair's last block much better) give the same bit-exact results, on
+    single pairs and on a ragged batch."""
+    from slam_amd import _lib, kernels
+    _lib.lib.slamhip_tune(3, threads)
+    _lib.lib.slamhip_tune(1, splits)
+    try:
+        rng = np.random.default_rng(threads + splits)
+        for nq, nt, d in [(1, 3, 61), (129, 300, 61), (610, 590, 61), (385, 77, 32), (128, 128, 128)]:
+            q = rng.integers(0, 4, (nq, d), dtype=np.uint8)      # few values: many equal distances
+            t = rng.integers(0, 4, (nt, d), dtype=np.uint8)
+            i, dd = _run(q, t)
+            ei, ed = so.hamming_knn2(q, t)
+            np.testing.assert_array_equal(i, ei, err_msg=f"{nq}x{nt}x{d}")
+            np.testing.assert_array_equal(dd, ed)
+        sizes = [(610, 600), (0, 5), (131, 0), (257, 640), (5, 1)]
+        qs = [rng.integers(0, 256, (a, 61), dtype=np.uint8) for a, _ in sizes]
+        ts = [rng.integers(0, 256, (b, 61), dtype=np.uint8) for _, b in sizes]
+        q_off = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.int32)
+        t_off = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.int32)
+        bi, bd = kernels.hamming_knn2_batched(np.concatenate(qs), np.concatenate(ts), q_off, t_off)
+        bi, bd = bi.cpu().numpy(), bd.cpu().numpy()
+        for p in range(len(sizes)):
+            ei, ed = so.hamming_knn2(qs[p], ts[p])
+            np.testing.assert_array_equal(bi[q_off[p]:q_off[p + 1]], ei, err_msg=f"pair {p}")
+            np.testing.assert_array_equal(bd[q_off[p]:q_off[p + 1]], ed)
+    finally:
+        _lib.lib.slamhip_tune(3, 0)
+        _lib.lib.slamhip_tune(1, 0)
+
+
 def test_empty_inputs():
     q = np.zeros((5, 61), np.uint8)
     i, d = _run(q, np.zeros((0, 61), np.uint8))
