@@ -304,6 +304,57 @@ __global__ __launch_bounds__(256) void cross_check_kernel(const int32_t *__restr
 }
 
 // ---------------------------------------------------------------------------
+// Stable order by (distance, query index) for segments of at most
+// kBitonicMax rows: one block sorts the segment's keys (dist << 21 | index,
+// unique, so an unstable network gives the stable order) in LDS with a bitonic
+// network and writes the index part.  O(n log^2 n) against the O(n^2) of rank
+// counting below, which remains for longer segments.
+// ---------------------------------------------------------------------------
+constexpr int kBitonicMax = 8192;
+
+__global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__restrict__ dist,
+                                                           int dist_stride, int n_single,
+                                                           const int32_t *__restrict__ off,
+                                                           const int32_t *__restrict__ cnt,
+                                                           int32_t *__restrict__ order) {
+  extern __shared__ uint32_t skeys[];
+  const int seg = blockIdx.x;
+  int s0 = 0, n = n_single;
+  if (off != nullptr) {
+    s0 = off[seg];
+    n = cnt ? cnt[seg] : off[seg + 1] - s0;
+  }
+  if (n <= 0) return;                       // block-uniform
+  int N = 1;
+  while (N < n) N <<= 1;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    uint32_t key = kNoKey;                  // padding sorts last
+    if (i < n) {
+      const int d = dist[(size_t)(s0 + i) * dist_stride];
+      key = ((d < 0 ? 2047u : (uint32_t)d) << kKeyShift) | (uint32_t)i;
+    }
+    skeys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= N; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (N >> 1); t += 256) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // t with a 0 inserted at bit log2(j)
+        const int hi = lo | j;
+        const uint32_t a = skeys[lo], b = skeys[hi];
+        const bool ascending = (lo & k) == 0;
+        if ((a > b) == ascending) {
+          skeys[lo] = b;
+          skeys[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int r = threadIdx.x; r < n; r += 256) order[s0 + r] = (int32_t)(skeys[r] & kIdxMask);
+}
+
+// ---------------------------------------------------------------------------
 // Stable order by (distance, query index) through rank counting: the keys
 // (dist << 21 | index) are unique, so rank(i) = #{j : key_j < key_i} and the
 // sorted sequence is order[rank(i)] = i.  2 VALU ops per (i, j) pair, all j
@@ -517,6 +568,23 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   return SLAMHIP_OK;
 }
 
+// Stable sort of every segment by (distance, index): LDS bitonic network (one block
+// per segment) when the segments fit it and there are enough of them to fill the
+// chip, rank counting (many blocks per segment) otherwise.
+void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int32_t *d_off,
+                 const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order, hipStream_t st) {
+  if (max_n <= kBitonicMax && n_segments >= 128) {
+    int N = 1;
+    while (N < max_n) N <<= 1;
+    hipLaunchKernelGGL(bitonic_sort_kernel, dim3(n_segments), dim3(256), (size_t)N * sizeof(uint32_t),
+                       st, d_dist, dist_stride, n_single, d_off, d_cnt, d_order);
+  } else {
+    const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
+    hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, st, d_dist, dist_stride, n_single, d_off,
+                       d_cnt, d_order);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -641,9 +709,8 @@ int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total
   if (n_total == 0 || max_n == 0) return SLAMHIP_OK;
   if (!d_dist || !d_order) return SLAMHIP_EINVAL;
   if (n_segments > 1 && !d_off) return SLAMHIP_EINVAL;
-  const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
-  hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_dist,
-                     dist_stride, d_off ? 0 : n_total, d_off, (const int32_t *)nullptr, d_order);
+  launch_sort(d_dist, dist_stride, d_off ? 0 : n_total, d_off, nullptr, n_segments, max_n, d_order,
+              (hipStream_t)stream);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }
@@ -685,9 +752,7 @@ int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_of
                      const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order,
                      hipStream_t st) {
   if (max_n <= 0 || n_segments <= 0) return SLAMHIP_OK;
-  const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
-  hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, st, d_dist, dist_stride, 0, d_off, d_cnt,
-                     d_order);
+  launch_sort(d_dist, dist_stride, 0, d_off, d_cnt, n_segments, max_n, d_order, st);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

@@ -169,6 +169,18 @@ def test_sort_large_and_segmented():
     o = kernels.sort_by_distance(dd, off=off).cpu().numpy()
     for s in range(len(sizes)):
         np.testing.assert_array_equal(o[off[s]:off[s + 1]], so.sort_by_distance(dd[off[s]:off[s + 1]]))
+    # single segments (rank counting): powers of two and their neighbours, absent distances (-1)
+    for n in (1, 2, 3, 255, 256, 257, 4097, 8191, 8192, 8193):
+        d = rng.integers(0, 12, n).astype(np.int32)
+        d[rng.random(n) < 0.05] = -1
+        np.testing.assert_array_equal(kernels.sort_by_distance(d).cpu().numpy(), so.sort_by_distance(d),
+                                      err_msg=f"n={n}")
+    sizes = [8192, 0, 5000, 8192, 17] + [int(v) for v in rng.integers(0, 700, 140)]   # >= 128 segments: network
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    dd = rng.integers(0, 1025, int(off[-1])).astype(np.int32)         # 128-byte rows: distances to 1024
+    o = kernels.sort_by_distance(dd, off=off).cpu().numpy()
+    for s in range(len(sizes)):
+        np.testing.assert_array_equal(o[off[s]:off[s + 1]], so.sort_by_distance(dd[off[s]:off[s + 1]]))
 
 
 @pytest.mark.parametrize("cross_check", [False, True])
