@@ -51,33 +51,37 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
     const uint8_t *__restrict__ src_a, int n_a, uint32_t *__restrict__ dst_a,
     const uint8_t *__restrict__ src_b, int n_b, uint32_t *__restrict__ dst_b, int desc_bytes,
     int stride, int log2W) {
-  // one thread per packed dword; W is a power of two, so row/word come from shifts
+  // one thread per four packed dwords (one 16-byte store); W is a power of two >= 8,
+  // so row / word group come from shifts
+  const int lq = log2W - 2;
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned total_a = (unsigned)n_a << log2W;
-  const unsigned total = total_a + ((unsigned)n_b << log2W);
+  const unsigned total_a = (unsigned)n_a << lq;
+  const unsigned total = total_a + ((unsigned)n_b << lq);
   if (gid >= total) return;
   const bool first = gid < total_a;
   const uint8_t *src = first ? src_a : src_b;
   uint32_t *dst = first ? dst_a : dst_b;
   const unsigned g = first ? gid : gid - total_a;
-  const unsigned r = g >> log2W;
-  const int w = (int)(g & ((1u << log2W) - 1u));
-  const uint8_t *p = src + (size_t)r * (size_t)stride + 4 * w;
-  const int valid = min(4, desc_bytes - 4 * w);  // bytes of this dword that belong to the row
-  uint32_t v = 0;
-  if (valid > 0) {
-    // Rows of 61 bytes start at any byte offset: fetch the one or two aligned dwords
-    // that hold the wanted bytes and funnel-shift.  Each of them contains a byte of
-    // the row, so neither can lie on a page the row does not touch.
-    const uintptr_t a = (uintptr_t)p;
-    const unsigned sh = (unsigned)(a & 3u);
-    const uint32_t *pa = reinterpret_cast<const uint32_t *>(a - sh);
-    const uint32_t lo = pa[0];
-    const uint32_t hi = ((int)sh + valid > 4) ? pa[1] : 0u;
-    v = __builtin_amdgcn_alignbyte(hi, lo, sh);
-    if (valid < 4) v &= (1u << (8 * valid)) - 1u;
+  const unsigned r = g >> lq;
+  const int w0 = 4 * (int)(g & ((1u << lq) - 1u));
+  // Rows of 61 bytes start at any byte offset: fetch the aligned dwords that hold the
+  // wanted 16 bytes and funnel-shift.  A dword is fetched only if it holds a byte of
+  // the row, so no access can fall on a page the row does not touch.
+  const int remaining = desc_bytes - 4 * w0;          // bytes of the row from this group on
+  const uintptr_t a = (uintptr_t)(src + (size_t)r * (size_t)stride + 4 * w0);
+  const unsigned sh = (unsigned)(a & 3u);
+  const uint32_t *pa = reinterpret_cast<const uint32_t *>(a - sh);
+  uint32_t d[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) d[k] = (4 * k < remaining + (int)sh) ? pa[k] : 0u;
+  uint32_t v[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const uint32_t x = __builtin_amdgcn_alignbyte(d[w + 1], d[w], sh);
+    const int valid = remaining - 4 * w;
+    v[w] = valid >= 4 ? x : (valid > 0 ? (x & ((1u << (8 * valid)) - 1u)) : 0u);
   }
-  dst[g] = v;
+  reinterpret_cast<uint4 *>(dst)[g] = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 // ---------------------------------------------------------------------------
@@ -517,8 +521,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     qp = (uint32_t *)d_query;
     tp = (uint32_t *)d_train;
   } else {
-    const long long total = ((long long)nq_total + nt_total) * p.W;
-    if (total >= (1ll << 32)) return SLAMHIP_EUNSUPPORTED;
+    const long long total = ((long long)nq_total + nt_total) * (p.W / 4);
+    if (total >= (1ll << 31)) return SLAMHIP_EUNSUPPORTED;
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, d_query, nq_total, qp,
                        d_train, nt_total, tp, desc_bytes, row_stride, p.W == 8 ? 3 : (p.W == 16 ? 4 : 5));
@@ -738,9 +742,9 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st) {
   const int W = slamhip_packed_words(desc_bytes);
-  const long long total = ((long long)n_a + n_b) * W;
+  const long long total = ((long long)n_a + n_b) * (W / 4);   // threads: one per four dwords
   if (total == 0) return SLAMHIP_OK;
-  if (total >= (1ll << 32)) return SLAMHIP_EUNSUPPORTED;
+  if (total >= (1ll << 31)) return SLAMHIP_EUNSUPPORTED;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_a,
                      n_a, d_dst_a, d_b, n_b, d_dst_b, desc_bytes, row_stride,
                      W == 8 ? 3 : (W == 16 ? 4 : 5));
