@@ -264,3 +264,31 @@ def test_frontend_result_builds_a_consistent_track_db():
         ids = np.asarray(db.track_ids[f])
         assert n_on_f == int((ids >= 0).sum()) == len(set(ids[ids >= 0].tolist()))
         assert len(db.all_frame_links(f)) == len(res.frame(f)["left_idx"])
+
+
+def test_batched_ransac_flags_the_all_inlier_case():
+    """The same noise-free frame three times: every temporal match is right and some
+    hypothesis has every correspondence as an inlier, where the reference's loop
+    raises `math domain error`
+    (pnp.py:150-153, pinned by ref_ransac_loop.npz case `all_inliers`).  The batched
+    path cannot raise per pair: it sets the pair's domain_error flag, stops at that
+    hypothesis and still returns its pose and an all-true mask."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=3, n_features=300, seed=9, clutter=0.0, pixel_sigma=0.0, bit_noise=0.0)
+    f = seq.frame(0)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right)] * 3
+    res = TrackingFrontend(cam, pixel_thresh=4.0, seed=1).run(frames)
+    flagged = 0
+    for p in range(2):
+        pr = res.pair(p)
+        if pr["domain_error"]:
+            flagged += 1
+            assert pr["best_count"] == pr["n_matches"] and pr["mask"].all()
+            assert pr["iterations"] == pr["best_index"] + 1          # stopped right there
+            assert np.abs(pr["Rt"] - np.hstack([np.eye(3), np.zeros((3, 1))])).max() < 1e-4
+        else:
+            assert pr["best_count"] < pr["n_matches"]
+    assert flagged == 2
