@@ -202,7 +202,9 @@ def test_run_sequence_tool_from_feature_cache(tmp_path):
         np.testing.assert_array_equal(back.pair(p)["mask"], res.pair(p)["mask"])
 
 
-def test_ransac_rounds_equal_stand_alone_kernels():
+@pytest.mark.parametrize("seed,n_iter,clutter,thresh", [(31, 1100, 0.72, 4.0), (5, 257, 0.5, 2.0),
+                                                        (77, 2500, 0.8, 1.5)])
+def test_ransac_rounds_equal_stand_alone_kernels(seed, n_iter, clutter, thresh):
     """The batched RANSAC (rounds of 256 hypotheses, late rounds on the narrow
     grid, hypotheses beyond the current requirement not generated) against the
     same samples pushed through the stand-alone kernels one pair at a time:
@@ -214,16 +216,15 @@ def test_ransac_rounds_equal_stand_alone_kernels():
     from slam_amd.backend.tracking.frontend import TrackingFrontend
     from slam_amd.utils.synth import StereoSequence
     cam = CameraModel.kitti_like()
-    seq = StereoSequence(cam, n_frames=7, n_features=900, seed=31, clutter=0.72, bit_noise=0.05)
+    seq = StereoSequence(cam, n_frames=7, n_features=900, seed=seed, clutter=clutter, bit_noise=0.05)
     frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(7))]
     frames[3] = tuple(a[:350] for a in frames[3])          # a sparse frame: its pairs behave differently
-    n_iter = 1100
-    counts = TrackingFrontend(cam, n_iter_max=1).run(frames).to_host()["st_count"]
-    rng = np.random.default_rng(77)
+    counts = TrackingFrontend(cam, pixel_thresh=thresh, n_iter_max=1).run(frames).to_host()["st_count"]
+    rng = np.random.default_rng(seed + 46)
     samples = np.zeros((6, n_iter, 4), np.int32)
     for p in range(6):
         samples[p] = np.stack([rng.choice(int(counts[p]), 4, replace=False) for _ in range(n_iter)])
-    res = TrackingFrontend(cam, n_iter_max=n_iter).run(frames, samples=samples)
+    res = TrackingFrontend(cam, pixel_thresh=thresh, n_iter_max=n_iter).run(frames, samples=samples)
     iters = []
     for p in range(6):
         got = res.pair(p)
@@ -231,16 +232,16 @@ def test_ransac_rounds_equal_stand_alone_kernels():
         X = a["xyz"][got["query_idx"]]
         pL, pR = b["pix_left"][got["train_idx"]], b["pix_right"][got["train_idx"]]
         Rts, valid = kernels.p3p_solve_indexed(X, pL, samples[p], cam.K)
-        c = kernels.ransac_score(X, pL, pR, Rts, valid, cam.K, cam.M_right, 4.0)
+        c = kernels.ransac_score(X, pL, pR, Rts, valid, cam.K, cam.M_right, thresh)
         rep = kernels.ransac_replay(c, len(X), 0.99999, n_iter).cpu().numpy()
         assert (got["best_index"], got["best_count"], got["iterations"], got["n_iter_required"]) == \
                (rep[0], rep[1], rep[2], rep[3]), (p, rep[:4])
         np.testing.assert_array_equal(got["Rt_ransac"], Rts.cpu().numpy()[rep[0]])
-        mask = kernels.ransac_mask(X, pL, pR, got["Rt_ransac"], cam.K, cam.M_right, 4.0).cpu().numpy()
+        mask = kernels.ransac_mask(X, pL, pR, got["Rt_ransac"], cam.K, cam.M_right, thresh).cpu().numpy()
         np.testing.assert_array_equal(got["mask"], mask.astype(bool))
         iters.append(int(got["iterations"]))
-    # the case must actually reach the late rounds and stop in different ones
-    assert max(iters) > 768 and min(iters) < max(iters), iters
+    if n_iter == 1100:   # this case must actually reach the late rounds and stop in different ones
+        assert max(iters) > 768 and min(iters) < max(iters), iters
 
 
 def test_frontend_result_builds_a_consistent_track_db():
