@@ -148,10 +148,12 @@ int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total
 /*             in OpenCV); out_fp64=1: divided in fp64.                      */
 /* keypoints are (n,2) float32 (fp64 if kp_fp64=1).  d_keep may be NULL      */
 /* (no filtering: every match is triangulated).  If d_keep is given, xyz of  */
-/* rejected matches is written as 0.                                         */
+/* rejected matches is written as 0.  n_left / n_right = rows of the two     */
+/* keypoint arrays: a match naming a row outside them (e.g. the matcher's -1 */
+/* for "no neighbour") is rejected (keep 0, xyz 0) and nothing is read.      */
 /* ------------------------------------------------------------------------- */
-int slamhip_stereo_filter_triangulate(const void *d_kp_left, const void *d_kp_right,
-                                      int kp_fp64, const int32_t *d_qidx,
+int slamhip_stereo_filter_triangulate(const void *d_kp_left, int n_left, const void *d_kp_right,
+                                      int n_right, int kp_fp64, const int32_t *d_qidx,
                                       const int32_t *d_tidx, int m, const double *P_left,
                                       const double *P_right, double pix_thresh,
                                       double disp_min, uint8_t *d_keep, void *d_xyz,
@@ -191,8 +193,10 @@ int slamhip_ransac_mask(const void *d_points, int points_fp64, const float *d_me
  * first three give up to four poses (P3P); the fourth selects the one with the
  * smallest reprojection error in normalised image coordinates.  d_Rt (h,3,4)
  * fp64, d_valid (h) uint8 (0 = no real solution with positive depths: the
- * reference's `None`).  K is a HOST pointer (9 doubles). */
-int slamhip_p3p_solve(const void *d_points, int points_fp64, const float *d_pixels,
+ * reference's `None`).  n_points = number of rows of d_points / d_pixels: a
+ * hypothesis naming a row outside [0, n_points) is reported invalid and nothing
+ * is read for it.  K is a HOST pointer (9 doubles). */
+int slamhip_p3p_solve(const void *d_points, int points_fp64, const float *d_pixels, int n_points,
                       const int32_t *d_idx4, int h, const double *K, double *d_Rt,
                       uint8_t *d_valid, void *stream);
 

@@ -57,10 +57,10 @@ SIGNATURES = {
     "slamhip_cross_check": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "slamhip_sort_by_distance": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "slamhip_stereo_filter_triangulate": (
-        _i, [_vp, _vp, _i, _vp, _vp, _i, _dp, _dp, _d, _d, _vp, _vp, _i, _vp]),
+        _i, [_vp, _i, _vp, _i, _i, _vp, _vp, _i, _dp, _dp, _d, _d, _vp, _vp, _i, _vp]),
     "slamhip_ransac_score": (_i, [_vp, _i, _vp, _vp, _i, _vp, _vp, _i, _dp, _dp, _d, _vp, _vp]),
     "slamhip_ransac_mask": (_i, [_vp, _i, _vp, _vp, _i, _vp, _dp, _dp, _d, _vp, _vp]),
-    "slamhip_p3p_solve": (_i, [_vp, _i, _vp, _vp, _i, _dp, _vp, _vp, _vp]),
+    "slamhip_p3p_solve": (_i, [_vp, _i, _vp, _i, _vp, _i, _dp, _vp, _vp, _vp]),
     "slamhip_refine_pose": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _dp, _vp, _i, _vp, _vp, _vp]),
     "slamhip_project": (_i, [_vp, _i, _i, _dp, _vp, _vp]),
     "slamhip_supporters_pair": (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp]),

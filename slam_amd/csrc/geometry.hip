@@ -22,7 +22,7 @@ using namespace slamhip_dev;
 
 template <typename KP>
 __global__ __launch_bounds__(256) void filter_triangulate_kernel(
-    const KP *__restrict__ kp_left, const KP *__restrict__ kp_right,
+    const KP *__restrict__ kp_left, int n_left, const KP *__restrict__ kp_right, int n_right,
     const int32_t *__restrict__ qidx, const int32_t *__restrict__ tidx, int m, CamPair cam,
     double pix_thresh, double disp_min, uint8_t *__restrict__ keep, void *__restrict__ xyz,
     int out_fp64) {
@@ -30,14 +30,19 @@ __global__ __launch_bounds__(256) void filter_triangulate_kernel(
   if (k >= m) return;
   const int li = qidx ? qidx[k] : k;
   const int ri = tidx ? tidx[k] : k;
-  const double uL = (double)kp_left[2 * (size_t)li + 0];
-  const double vL = (double)kp_left[2 * (size_t)li + 1];
-  const double uR = (double)kp_right[2 * (size_t)ri + 0];
-  const double vR = (double)kp_right[2 * (size_t)ri + 1];
+  // a match naming a keypoint that does not exist is rejected and nothing is read for it
+  const bool in_range = li >= 0 && li < n_left && ri >= 0 && ri < n_right;
+  double uL = 0.0, vL = 0.0, uR = 0.0, vR = 0.0;
+  if (in_range) {
+    uL = (double)kp_left[2 * (size_t)li + 0];
+    vL = (double)kp_left[2 * (size_t)li + 1];
+    uR = (double)kp_right[2 * (size_t)ri + 0];
+    vR = (double)kp_right[2 * (size_t)ri + 1];
+  }
 
-  bool ok = true;
+  bool ok = in_range;
   if (keep != nullptr) {
-    ok = stereo_keep(uL, vL, uR, vR, pix_thresh, disp_min);
+    ok = in_range && stereo_keep(uL, vL, uR, vR, pix_thresh, disp_min);
     keep[k] = ok ? 1 : 0;
   }
 
@@ -69,7 +74,8 @@ __global__ __launch_bounds__(256) void filter_triangulate_kernel(
 
 }  // namespace
 
-extern "C" int slamhip_stereo_filter_triangulate(const void *d_kp_left, const void *d_kp_right,
+extern "C" int slamhip_stereo_filter_triangulate(const void *d_kp_left, int n_left,
+                                                 const void *d_kp_right, int n_right,
                                                  int kp_fp64, const int32_t *d_qidx,
                                                  const int32_t *d_tidx, int m,
                                                  const double *P_left, const double *P_right,
@@ -77,9 +83,10 @@ extern "C" int slamhip_stereo_filter_triangulate(const void *d_kp_left, const vo
                                                  uint8_t *d_keep, void *d_xyz, int out_fp64,
                                                  void *stream) {
   SLAMHIP_BEGIN();
-  if (m < 0) return SLAMHIP_EINVAL;
+  if (m < 0 || n_left < 0 || n_right < 0) return SLAMHIP_EINVAL;
   if (m == 0) return SLAMHIP_OK;
-  if (!d_kp_left || !d_kp_right || !P_left || !P_right || !d_xyz) return SLAMHIP_EINVAL;
+  if (!P_left || !P_right || !d_xyz) return SLAMHIP_EINVAL;
+  if ((n_left > 0 && !d_kp_left) || (n_right > 0 && !d_kp_right)) return SLAMHIP_EINVAL;
   CamPair cam;
   for (int i = 0; i < 12; ++i) {
     cam.PL[i] = P_left[i];
@@ -89,11 +96,11 @@ extern "C" int slamhip_stereo_filter_triangulate(const void *d_kp_left, const vo
   hipStream_t st = (hipStream_t)stream;
   if (kp_fp64)
     hipLaunchKernelGGL(filter_triangulate_kernel<double>, grid, block, 0, st,
-                       (const double *)d_kp_left, (const double *)d_kp_right, d_qidx, d_tidx, m,
+                       (const double *)d_kp_left, n_left, (const double *)d_kp_right, n_right, d_qidx, d_tidx, m,
                        cam, pix_thresh, disp_min, d_keep, d_xyz, out_fp64);
   else
     hipLaunchKernelGGL(filter_triangulate_kernel<float>, grid, block, 0, st,
-                       (const float *)d_kp_left, (const float *)d_kp_right, d_qidx, d_tidx, m,
+                       (const float *)d_kp_left, n_left, (const float *)d_kp_right, n_right, d_qidx, d_tidx, m,
                        cam, pix_thresh, disp_min, d_keep, d_xyz, out_fp64);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;

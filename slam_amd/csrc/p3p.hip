@@ -28,15 +28,27 @@ using namespace slamhip_dev;
 
 template <typename PT>
 __global__ __launch_bounds__(64) void p3p_kernel(const PT *__restrict__ pts,
-                                                 const float *__restrict__ pix,
+                                                 const float *__restrict__ pix, int n_points,
                                                  const int32_t *__restrict__ idx4, int h, Kinv ki,
                                                  double *__restrict__ Rt_out,
                                                  uint8_t *__restrict__ valid_out) {
   const int hyp = blockIdx.x * blockDim.x + threadIdx.x;
   if (hyp >= h) return;
   double X[4][3], f[4][3], nrm4[2];
+  long long rows[4];
+  bool in_range = true;
   for (int k = 0; k < 4; ++k) {
-    const size_t r = idx4 ? (size_t)idx4[4 * (size_t)hyp + k] : (size_t)(4 * (size_t)hyp + k);
+    rows[k] = idx4 ? (long long)idx4[4 * (size_t)hyp + k] : 4ll * hyp + k;
+    in_range = in_range && rows[k] >= 0 && rows[k] < (long long)n_points;
+  }
+  double *out = Rt_out + 12 * (size_t)hyp;
+  if (!in_range) {            // a sample naming a row that does not exist: no pose, nothing read
+    valid_out[hyp] = 0;
+    for (int i = 0; i < 12; ++i) out[i] = 0.0;
+    return;
+  }
+  for (int k = 0; k < 4; ++k) {
+    const size_t r = (size_t)rows[k];
     for (int c = 0; c < 3; ++c) X[k][c] = (double)pts[3 * r + c];
     double nk[2];
     pixel_to_bearing(ki, (double)pix[2 * r + 0], (double)pix[2 * r + 1], f[k], nk);
@@ -45,7 +57,6 @@ __global__ __launch_bounds__(64) void p3p_kernel(const PT *__restrict__ pts,
   double Rt[12];
   const bool found = p3p_lane(X, f, nrm4, Rt);
   valid_out[hyp] = found ? 1 : 0;
-  double *out = Rt_out + 12 * (size_t)hyp;
   for (int i = 0; i < 12; ++i) out[i] = found ? Rt[i] : 0.0;
 }
 
@@ -63,10 +74,10 @@ bool invert3(const double *K, double *o) {
 }  // namespace
 
 extern "C" int slamhip_p3p_solve(const void *d_points, int points_fp64, const float *d_pixels,
-                                 const int32_t *d_idx4, int h, const double *K, double *d_Rt,
-                                 uint8_t *d_valid, void *stream) {
+                                 int n_points, const int32_t *d_idx4, int h, const double *K,
+                                 double *d_Rt, uint8_t *d_valid, void *stream) {
   SLAMHIP_BEGIN();
-  if (h < 0) return SLAMHIP_EINVAL;
+  if (h < 0 || n_points < 0) return SLAMHIP_EINVAL;
   if (h == 0) return SLAMHIP_OK;
   if (!d_points || !d_pixels || !K || !d_Rt || !d_valid) return SLAMHIP_EINVAL;
   Kinv ki;
@@ -74,10 +85,10 @@ extern "C" int slamhip_p3p_solve(const void *d_points, int points_fp64, const fl
   const dim3 grid(slamhip_ceil_div(h, 64)), block(64);
   if (points_fp64)
     hipLaunchKernelGGL(p3p_kernel<double>, grid, block, 0, (hipStream_t)stream,
-                       (const double *)d_points, d_pixels, d_idx4, h, ki, d_Rt, d_valid);
+                       (const double *)d_points, d_pixels, n_points, d_idx4, h, ki, d_Rt, d_valid);
   else
     hipLaunchKernelGGL(p3p_kernel<float>, grid, block, 0, (hipStream_t)stream,
-                       (const float *)d_points, d_pixels, d_idx4, h, ki, d_Rt, d_valid);
+                       (const float *)d_points, d_pixels, n_points, d_idx4, h, ki, d_Rt, d_valid);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

@@ -729,9 +729,10 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
 
   // per keyframe: points of all stored features (loop_closure.py:179-180,237-249: fp64
   // triangulation, later cast to float32 at :209) and packed descriptors
-  int rc = slamhip_stereo_filter_triangulate(a->d_kp_left, a->d_kp_right, 1, nullptr, nullptr,
-                                             a->n_rows_total, a->P_left, a->P_right, 0.0, 0.0,
-                                             nullptr, a->d_xyz, 2, stream);
+  int rc = slamhip_stereo_filter_triangulate(a->d_kp_left, a->n_rows_total, a->d_kp_right,
+                                             a->n_rows_total, 1, nullptr, nullptr, a->n_rows_total,
+                                             a->P_left, a->P_right, 0.0, 0.0, nullptr, a->d_xyz, 2,
+                                             stream);
   if (rc) return rc;
   rc = slamhip_internal::pack_rows(a->d_des, a->n_rows_total, packed, nullptr, 0, nullptr,
                                    a->desc_bytes, a->desc_stride, st);

@@ -210,7 +210,7 @@ def stereo_filter_triangulate(kp_left, kp_right, qidx, tidx, P_left, P_right,
     pl, _a = _lib.host_doubles(P_left, 12)
     pr, _b = _lib.host_doubles(P_right, 12)
     check(lib.slamhip_stereo_filter_triangulate(
-        _ptr(kl), _ptr(kr), 1 if fp64 else 0, _ptr(qi), _ptr(ti), m, pl, pr,
+        _ptr(kl), int(kl.shape[0]), _ptr(kr), int(kr.shape[0]), 1 if fp64 else 0, _ptr(qi), _ptr(ti), m, pl, pr,
         float(pixel_thresh), float(disparity_min), _ptr(keep), _ptr(xyz), 1 if fp64 else 0,
         _stream()), "slamhip_stereo_filter_triangulate")
     return keep, xyz
@@ -305,8 +305,10 @@ def p3p_solve_indexed(points, pixels, idx4, K):
     Rts = torch.empty((h, 3, 4), dtype=torch.float64, device=pts.device)
     valid = torch.empty(h, dtype=torch.uint8, device=pts.device)
     kp, _a = _lib.host_doubles(K, 9)
-    check(lib.slamhip_p3p_solve(_ptr(pts), 1 if fp64 else 0, _ptr(pix), _ptr(ix), h, kp, _ptr(Rts),
-                                _ptr(valid), _stream()), "slamhip_p3p_solve")
+    if pix.shape[0] != pts.shape[0]:
+        raise ValueError("points and pixels differ in length")
+    check(lib.slamhip_p3p_solve(_ptr(pts), 1 if fp64 else 0, _ptr(pix), int(pts.shape[0]), _ptr(ix), h, kp,
+                                _ptr(Rts), _ptr(valid), _stream()), "slamhip_p3p_solve")
     return Rts, valid
 
 

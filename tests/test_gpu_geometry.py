@@ -115,3 +115,25 @@ def test_triangulation_facade(golden):
     rel2 = np.abs(X2 - ref2) / np.abs(ref2).max(axis=1, keepdims=True)
     assert rel2.max() < 1e-6
     assert tri.create_inlier_outlier_matches([], kpl, kpr) == ([], [])
+
+
+def test_matches_naming_missing_keypoints_are_rejected(golden):
+    """Index -1 (the matcher's "no neighbour") or a row past the end: keep 0, xyz 0,
+    nothing read; the other matches are unaffected."""
+    from slam_amd import kernels, CameraModel
+    g = golden("ref_stereo_filter.npz")
+    cam = CameraModel.kitti_like()
+    q, t = g["qidx"].copy(), g["tidx"].copy()
+    ref_keep, ref_xyz = kernels.stereo_filter_triangulate(g["kp_left"], g["kp_right"], q, t, cam.P_left,
+                                                          cam.P_right, 4.0, 1.2)
+    bad = [1, 7, 20]
+    t[bad[0]] = -1
+    q[bad[1]] = len(g["kp_left"])
+    t[bad[2]] = 2 ** 31 - 1
+    keep, xyz = kernels.stereo_filter_triangulate(g["kp_left"], g["kp_right"], q, t, cam.P_left, cam.P_right,
+                                                  4.0, 1.2)
+    keep, xyz, ref_keep, ref_xyz = (a.cpu().numpy() for a in (keep, xyz, ref_keep, ref_xyz))
+    assert not keep[bad].any() and not xyz[bad].any()
+    ok = np.ones(len(q), bool); ok[bad] = False
+    np.testing.assert_array_equal(keep[ok], ref_keep[ok])
+    np.testing.assert_array_equal(xyz[ok], ref_xyz[ok])

@@ -66,6 +66,17 @@ def test_p3p_degenerate_inputs_flagged_invalid():
     assert np.isfinite(Rts.cpu().numpy()).all()
 
 
+def test_p3p_out_of_range_sample_rows_are_invalid_not_read():
+    from slam_amd import kernels, CameraModel
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(3)
+    X, pix, _ = _scene(rng, 50, cam)
+    idx4 = np.array([[0, 1, 2, 3], [4, 5, 6, 50], [-1, 2, 3, 4], [7, 8, 9, 10], [2 ** 31 - 1, 0, 1, 2]], np.int32)
+    Rts, valid = kernels.p3p_solve_indexed(X, pix, idx4, cam.K)
+    assert valid.cpu().numpy().tolist() == [1, 0, 0, 1, 0]
+    assert not Rts.cpu().numpy()[[1, 2, 4]].any()
+
+
 def test_refine_reaches_least_squares_minimum():
     from slam_amd import kernels, CameraModel
     cam = CameraModel.kitti_like()
