@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__rest
                                                            int dist_stride, int n_single,
                                                            const int32_t *__restrict__ off,
                                                            const int32_t *__restrict__ cnt,
-                                                           int32_t *__restrict__ order) {
+                                                           int32_t *__restrict__ order, int lds_keys) {
   extern __shared__ uint32_t skeys[];
   const int seg = blockIdx.x;
   int s0 = 0, n = n_single;
@@ -328,7 +328,9 @@ __global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__rest
     s0 = off[seg];
     n = cnt ? cnt[seg] : off[seg + 1] - s0;
   }
-  if (n <= 0) return;                       // block-uniform
+  // block-uniform; a segment longer than the caller's stated maximum does not fit the
+  // LDS that was sized from it and is left alone rather than sorted out of bounds
+  if (n <= 0 || n > lds_keys) return;
   int N = 1;
   while (N < n) N <<= 1;
   for (int i = threadIdx.x; i < N; i += 256) {
@@ -581,7 +583,7 @@ void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int
     int N = 1;
     while (N < max_n) N <<= 1;
     hipLaunchKernelGGL(bitonic_sort_kernel, dim3(n_segments), dim3(256), (size_t)N * sizeof(uint32_t),
-                       st, d_dist, dist_stride, n_single, d_off, d_cnt, d_order);
+                       st, d_dist, dist_stride, n_single, d_off, d_cnt, d_order, N);
   } else {
     const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
     hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, st, d_dist, dist_stride, n_single, d_off,
