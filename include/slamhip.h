@@ -303,9 +303,11 @@ int slamhip_frontend_batch(const slamhip_frontend_args *args, void *stream);
 /* current keyframe's (train), k=1, sorted by distance; P3D = candidate      */
 /* points by queryIdx, pixels of the current keyframe by trainIdx (float32); */
 /* pairs with fewer than min_points matches are not attempted (:206-207);    */
-/* adaptive P3P RANSAC with stereo consensus; LM refinement on the inliers.  */
-/* The caller applies the `mask.sum() < min_inliers` test (:218-219) to      */
-/* d_info[8p+6] and inverts the pose (:226-228).                             */
+/* adaptive P3P RANSAC with stereo consensus; LM refinement on the inliers   */
+/* of the pairs whose consensus set has at least min_points members (the     */
+/* others get their RANSAC pose back: the reference returns before refining, */
+/* :218-219).  The caller applies the same `mask.sum() < min_inliers` test   */
+/* to d_info[8p+6] and inverts the pose (:226-228).                          */
 /*                                                                           */
 /* Pair p reads query rows [d_qbase[p], +d_qcnt[p]) and train rows           */
 /* [d_tbase[p], +d_tcnt[p]) of the per-keyframe arrays; its per-match        */

@@ -53,5 +53,5 @@ int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_of
 int refine_pose(const void *d_points, int points_fp64, const float *d_pixels, const uint8_t *d_mask,
                 const int32_t *d_off, const int32_t *d_cnt, int n_problems, const double *K,
                 const double *d_Rt_init, int max_iters, double *d_Rt_out, double *d_info,
-                hipStream_t st);
+                hipStream_t st, const int32_t *d_ransac_info = nullptr, int min_inliers = 0);
 }  // namespace slamhip_internal

@@ -776,7 +776,8 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
     if (rc) return rc;
     rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, ob, tcount + c0, np, a->K,
                                        a->d_pose_ransac + 12 * (size_t)c0, a->refine_iters,
-                                       a->d_pose_refined + 12 * (size_t)c0, nullptr, st);
+                                       a->d_pose_refined + 12 * (size_t)c0, nullptr, st,
+                                       a->d_info + 8 * (size_t)c0, a->min_points);
     if (rc) return rc;
   }
   return SLAMHIP_OK;
