@@ -52,7 +52,9 @@ const char *slamhip_strerror(int code);
  * (-1 auto), knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
  * screening in the consensus counting kernels (1 = on, the default; 0 = fp64 only;
  * the counts are identical either way), knob 3 = matcher block size (0 auto, 256 or
- * 128 queries per block).  Process-global; not for use while other
+ * 128 queries per block), knob 4 = pair RANSAC launch scheme (0 auto: calls with at
+ * most 64 pairs solve and count every hypothesis in one pass; 1 always rounds of 256
+ * hypotheses; identical results; set it before sizing a workspace).  Process-global; not for use while other
  * threads are inside the library. */
 int slamhip_tune(int knob, int value);
 

@@ -31,6 +31,9 @@ namespace slamhip_internal {
 // 1: consensus counting screens in packed fp32 and re-evaluates undecided points in
 // fp64 (same counts); 0: fp64 only.  Set through slamhip_tune(2, value).
 extern int g_ransac_screen;
+// Pair RANSAC launch scheme: 0 = chosen from the number of pairs (single pass for few
+// pairs), 1 = always rounds of 256 hypotheses.  Set through slamhip_tune(4, value).
+extern int g_ransac_mode;
 
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                             int desc_bytes, long long n_out = -1, bool prepacked = false);

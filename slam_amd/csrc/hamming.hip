@@ -599,12 +599,14 @@ extern "C" {
 // variant (-1 auto; bit0 LDS-staged train tile, value>>1 = queries per lane),
 // knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
 // screening in the consensus counting kernels (1 on, 0 fp64 only; same counts),
-// knob 3 = matcher block size (0 auto, 256, 128).
+// knob 3 = matcher block size (0 auto, 256, 128), knob 4 = pair RANSAC launch scheme
+// (0 auto, 1 always rounds; set it before sizing the workspace).
 int slamhip_tune(int knob, int value) {
   if (knob == 0) g_force_variant = value;
   else if (knob == 1) g_force_splits = value;
   else if (knob == 2) slamhip_internal::g_ransac_screen = value ? 1 : 0;
   else if (knob == 3) g_force_threads = value;
+  else if (knob == 4) slamhip_internal::g_ransac_mode = value;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
 }

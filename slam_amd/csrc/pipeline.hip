@@ -281,46 +281,57 @@ struct RansacParams {
   long long pair0;  // index of the launch's first pair in the caller's numbering (sampling)
 };
 
-// Pose table layout: rt[(pair * 12 + element) * kHypPerRound + lane].
+// grid (pairs, slots).  A launch covers `slots` consecutive blocks of kHypPerRound
+// hypotheses per pair: 1 in the round scheme; all of them (round 0 only, no replay
+// in between) when a call has so few pairs that launches, not arithmetic, bound it.
+// Pose table layout: rt[((pair * slots + slot) * 12 + element) * kHypPerRound + lane].
 __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
-    int round, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    int round, int slots, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
     int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info) {
   __shared__ int sh[3];  // stopped, winner lane of the replayed round, iterations required
   __shared__ int red[4 + kBlock / 64];
-  const int p = blockIdx.x;
+  const int p = blockIdx.x, slot = blockIdx.y;
+  const size_t row = (size_t)p * slots + slot;      // this block's row of the pose / count tables
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
   int winner = -1;
   if (round == 0) {
+    // every slot's block works out the same start state; slot 0 records it
+    const int skip = (n >= 4 && n >= prm.min_points) ? 0 : 1;
     if (threadIdx.x == 0) {
-      s[0] = -1; s[1] = 0; s[2] = 0; s[3] = prm.n_iter_max; s[4] = 0; s[5] = n; s[6] = 0;
-      s[7] = (n >= 4 && n >= prm.min_points) ? 0 : 1;
+      if (slot == 0) {
+        s[0] = -1; s[1] = 0; s[2] = 0; s[3] = prm.n_iter_max; s[4] = 0; s[5] = n; s[6] = 0;
+        s[7] = skip;
+      }
+      sh[0] = skip;
+      sh[1] = -1;
+      sh[2] = prm.n_iter_max;
     }
-  } else if (!s[7]) {      // same value in every thread: written by an earlier launch
-    winner = replay_round(s, counts + (size_t)p * kHypPerRound, round - 1, n, prm.n_iter_max,
-                          log(1.0 - prm.p_success), red);
-  }
-  if (threadIdx.x == 0) {
-    sh[0] = s[7];
-    sh[1] = winner;
-    sh[2] = s[3];
+  } else {                 // round scheme only (slots == 1)
+    if (!s[7])             // same value in every thread: written by an earlier launch
+      winner = replay_round(s, counts + row * kHypPerRound, round - 1, n, prm.n_iter_max,
+                            log(1.0 - prm.p_success), red);
+    if (threadIdx.x == 0) {
+      sh[0] = s[7];
+      sh[1] = winner;
+      sh[2] = s[3];
+    }
   }
   __syncthreads();
-  if (threadIdx.x < 12) {
+  if (threadIdx.x < 12 && slot == 0) {
     if (round == 0)
       pose_ransac[12 * (size_t)p + threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;  // [I|0]
     else if (sh[1] >= 0)
-      pose_ransac[12 * (size_t)p + threadIdx.x] =
-          rt[((size_t)p * 12 + threadIdx.x) * kHypPerRound + sh[1]];
+      pose_ransac[12 * (size_t)p + threadIdx.x] = rt[(row * 12 + threadIdx.x) * kHypPerRound + sh[1]];
   }
   if (sh[0]) return;
   __syncthreads();  // the winner has been read before its slot is overwritten
 
   // The required iteration count only ever shrinks, so a hypothesis at or beyond the
   // current requirement can never be consumed by the replay: it is not generated.
-  const int it = round * kHypPerRound + (int)threadIdx.x;
+  const int it = (round * slots + slot) * kHypPerRound + (int)threadIdx.x;
   const bool active = it < prm.n_iter_max && it < sh[2];
   bool valid = false;
   if (active) {
@@ -355,12 +366,12 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
     }
     valid = p3p_lane(Xs, f, nrm4, Rt);
     if (valid)
-      for (int i = 0; i < 12; ++i) rt[((size_t)p * 12 + i) * kHypPerRound + threadIdx.x] = Rt[i];
+      for (int i = 0; i < 12; ++i) rt[(row * 12 + i) * kHypPerRound + threadIdx.x] = Rt[i];
   }
-  counts[(size_t)p * kHypPerRound + threadIdx.x] = active ? (valid ? 0 : -1) : -2;
+  counts[row * kHypPerRound + threadIdx.x] = active ? (valid ? 0 : -1) : -2;
 }
 
-// grid (point spans, kHypPerRound / 64, pairs), one wavefront per block; a span is
+// grid (point spans, slots * kHypPerRound / 64, pairs), one wavefront per block; a span is
 // `chunks_per_span` LDS-staged chunks of kPtsPerChunk correspondences.  The first
 // rounds, which most pairs need, use one chunk per block for parallelism; later
 // rounds, which few pairs reach, use one block per 64 hypotheses so that a launch
@@ -371,16 +382,17 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span, int screened) {
+    const int32_t *__restrict__ info, int chunks_per_span, int screened, int slots) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p = blockIdx.z;
+  const size_t row = (size_t)p * slots + blockIdx.y / (kHypPerRound / 64);
   if (info[8 * (size_t)p + 7]) return;
   const int n = tm_count[p];
   const int span0 = blockIdx.x * (chunks_per_span * kPtsPerChunk);
   if (span0 >= n) return;
   const int span1 = min(n, span0 + chunks_per_span * kPtsPerChunk);
-  const int hyp = blockIdx.y * 64 + (int)threadIdx.x;
-  int32_t *slot = counts + (size_t)p * kHypPerRound + hyp;
+  const int hyp = (int)(blockIdx.y % (kHypPerRound / 64)) * 64 + (int)threadIdx.x;
+  int32_t *slot = counts + row * kHypPerRound + hyp;
   // a valid hypothesis' slot starts at 0 and only grows; invalid ones hold -1 / -2
   const bool valid = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
   if (!__any(valid)) return;
@@ -389,7 +401,7 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
     double Rt[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i)
-      Rt[i] = valid ? rt[((size_t)p * 12 + i) * kHypPerRound + hyp] : 0.0;
+      Rt[i] = valid ? rt[(row * 12 + i) * kHypPerRound + hyp] : 0.0;
     make_projections(Rt, cam, PL, PR);
   }
   Hyp32 h32;
@@ -424,10 +436,11 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
   if (valid && c) atomicAdd(slot, c);
 }
 
-// Replays the last round, then writes the winner's mask, its count and the
-// final info record.
+// Replays the hypothesis blocks not replayed yet (the last round's one, or all
+// `slots` of a single-pass call, in order), then writes the winner's mask, its
+// count and the final info record.  `first_block` = index of the first of them.
 __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
-    int rounds, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    int first_block, int slots, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     RansacParams prm, const double *__restrict__ rt, const int32_t *__restrict__ counts,
     double *__restrict__ pose_ransac, uint8_t *__restrict__ tm_mask, int32_t *__restrict__ info) {
@@ -437,10 +450,15 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
   __shared__ int red[4 + kBlock / 64];
-  int winner = -1;
-  if (!s[7])               // same value in every thread: written by an earlier launch
-    winner = replay_round(s, counts + (size_t)p * kHypPerRound, rounds - 1, n, prm.n_iter_max,
-                          log(1.0 - prm.p_success), red);
+  int winner = -1, winner_slot = 0;
+  const double log1mp = log(1.0 - prm.p_success);
+  for (int k = 0; k < slots; ++k) {
+    if (s[7]) break;       // same value in every thread: written before the barrier below
+    const int w = replay_round(s, counts + ((size_t)p * slots + k) * kHypPerRound, first_block + k, n,
+                               prm.n_iter_max, log1mp, red);
+    if (w >= 0) { winner = w; winner_slot = k; }
+    __syncthreads();       // thread 0's state update is visible to the next pass
+  }
   if (threadIdx.x == 0) {
     sh[0] = winner;
     sh[1] = s[0] >= 0;
@@ -448,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
   }
   __syncthreads();
   if (threadIdx.x < 12) {
-    const double v = sh[0] >= 0 ? rt[((size_t)p * 12 + threadIdx.x) * kHypPerRound + sh[0]]
+    const double v = sh[0] >= 0 ? rt[(((size_t)p * slots + winner_slot) * 12 + threadIdx.x) * kHypPerRound + sh[0]]
                                 : pose_ransac[12 * (size_t)p + threadIdx.x];
     best_rt[threadIdx.x] = v;
     pose_ransac[12 * (size_t)p + threadIdx.x] = v;
@@ -478,10 +496,31 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
   if (threadIdx.x == 0) { s[5] = n; s[6] = sh[2]; s[7] = 0; }
 }
 
-size_t ransac_workspace_bytes(int n_pairs) {
+// A call with few pairs is bound by its dependent launches, not by arithmetic: it
+// solves and counts every hypothesis of the cap in one pass (kMaxSlots blocks of
+// kHypPerRound at most) and replays them all in the finishing launch -- 3 launches
+// instead of 2 per round.  Same samples, same replay order, same outcome.
+constexpr int kMaxSlots = 16;
+constexpr int kSinglePassPairs = 64;    // measured break-even against the adaptive rounds at ~40 % inliers
+
+int single_pass_slots(int n_pairs, int n_iter_max) {
+  const int slots = slamhip_ceil_div(n_iter_max > 0 ? n_iter_max : 1, kHypPerRound);
+  const int mode = slamhip_internal::g_ransac_mode;      // 0 auto, 1 rounds always
+  if (slots < 2 || slots > kMaxSlots || mode == 1) return 1;
+  if (n_pairs > kSinglePassPairs) return 1;
+  return slots;
+}
+
+// Sized for any call with at most n_pairs pairs (a caller may run its last, shorter
+// batch through the same workspace, and a short batch may take the single pass).
+size_t ransac_workspace_bytes(int n_pairs, int n_iter_max) {
   const size_t g = (size_t)(n_pairs < kPairGroup ? (n_pairs > 0 ? n_pairs : 1) : kPairGroup);
-  return slamhip_align_up(g * 12 * kHypPerRound * sizeof(double), 256) +
-         slamhip_align_up(g * kHypPerRound * sizeof(int32_t), 256);
+  size_t rows = g;
+  const int most = n_pairs < kSinglePassPairs ? n_pairs : kSinglePassPairs;   // largest single-pass call
+  const size_t single = (size_t)most * single_pass_slots(most, n_iter_max);
+  if (single > rows) rows = single;
+  return slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256) +
+         slamhip_align_up(rows * kHypPerRound * sizeof(int32_t), 256);
 }
 
 // RANSAC for pairs [0, n_pairs) described by obase / tm_count; `prm.pair0` is
@@ -492,29 +531,32 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
                     hipStream_t st) {
   if (n_pairs <= 0) return SLAMHIP_OK;
   const int group = n_pairs < kPairGroup ? n_pairs : kPairGroup;
+  const int slots = single_pass_slots(n_pairs, prm.n_iter_max);
+  const size_t rows = (size_t)group * slots;
   double *rt = (double *)ws;
   int32_t *counts =
-      (int32_t *)((uintptr_t)ws + slamhip_align_up((size_t)group * 12 * kHypPerRound * sizeof(double), 256));
-  const int rounds = slamhip_ceil_div(prm.n_iter_max, kHypPerRound);
+      (int32_t *)((uintptr_t)ws + slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256));
+  const int rounds = slots > 1 ? 1 : slamhip_ceil_div(prm.n_iter_max, kHypPerRound);
   const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
   const long long pair0 = prm.pair0;
   for (int g0 = 0; g0 < n_pairs; g0 += group) {
     const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
     prm.pair0 = pair0 + g0;
     for (int r = 0; r < rounds; ++r) {
-      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np), dim3(kBlock), 0, st, r, obase + g0,
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, slots), dim3(kBlock), 0, st, r, slots, obase + g0,
                          tm_count + g0, cx, cpl, samples, prm, rt, counts,
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
       hipLaunchKernelGGL(ransac_count_kernel,
-                         dim3(slamhip_ceil_div(chunks, per_span), kHypPerRound / 64, np), dim3(64), 0,
-                         st, obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,
-                         info + 8 * (size_t)g0, per_span, slamhip_internal::g_ransac_screen);
+                         dim3(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np),
+                         dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh,
+                         rt, counts, info + 8 * (size_t)g0, per_span, slamhip_internal::g_ransac_screen,
+                         slots);
     }
-    hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds, obase + g0,
-                       tm_count + g0, cx, cpl, cpr, prm, rt, counts, pose_ransac + 12 * (size_t)g0,
-                       tm_mask, info + 8 * (size_t)g0);
+    hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds - 1, slots,
+                       obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt, counts,
+                       pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
     SLAMHIP_CHECK_LAUNCH();
   }
   return SLAMHIP_OK;
@@ -545,7 +587,7 @@ Layout make_layout(const slamhip_frontend_args *a) {
   L.tidx2 = take(NL * 8); L.tdist2 = take(NL * 8); L.order2 = take(NL * 4);
   L.cx = take(NL * 12); L.cpl = take(NL * 8); L.cpr = take(NL * 8);
   L.tcount = take((size_t)F * 4);
-  L.ransac = take(ransac_workspace_bytes(F - 1));
+  L.ransac = take(ransac_workspace_bytes(F - 1, a->n_iter_max));
   L.total = o + 256;
   return L;
 }
@@ -693,7 +735,7 @@ size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
   take(slamhip_internal::knn2_workspace_bytes(a->n_rows_total, a->n_rows_total, chunk, a->max_q,
                                               a->max_t, a->desc_bytes, (long long)a->n_out_total,
                                               true));
-  take(ransac_workspace_bytes(chunk));
+  take(ransac_workspace_bytes(chunk, a->n_iter_max));
   return o + 256;
 }
 
@@ -725,7 +767,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
       a->n_rows_total, a->n_rows_total, chunk_max, a->max_q, a->max_t, a->desc_bytes,
       (long long)a->n_out_total, true);
   void *knn_ws = (void *)take(knn_bytes);
-  void *ransac_ws = (void *)take(ransac_workspace_bytes(chunk_max));
+  void *ransac_ws = (void *)take(ransac_workspace_bytes(chunk_max, a->n_iter_max));
 
   // per keyframe: points of all stored features (loop_closure.py:179-180,237-249: fp64
   // triangulation, later cast to float32 at :209) and packed descriptors

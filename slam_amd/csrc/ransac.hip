@@ -189,6 +189,7 @@ void fill_cam(RansacCam &cam, const double *K, const double *M_right) {
 }  // namespace
 
 int slamhip_internal::g_ransac_screen = 1;
+int slamhip_internal::g_ransac_mode = 0;
 
 extern "C" {
 

@@ -202,20 +202,30 @@ def test_run_sequence_tool_from_feature_cache(tmp_path):
         np.testing.assert_array_equal(back.pair(p)["mask"], res.pair(p)["mask"])
 
 
+@pytest.mark.parametrize("scheme", [1, 0])       # tune knob 4: 1 = rounds, 0 = auto (single pass here)
 @pytest.mark.parametrize("seed,n_iter,clutter,thresh", [(31, 1100, 0.72, 4.0), (5, 257, 0.5, 2.0),
                                                         (77, 2500, 0.8, 1.5)])
-def test_ransac_rounds_equal_stand_alone_kernels(seed, n_iter, clutter, thresh):
-    """The batched RANSAC (rounds of 256 hypotheses, late rounds on the narrow
-    grid, hypotheses beyond the current requirement not generated) against the
+def test_ransac_rounds_equal_stand_alone_kernels(seed, n_iter, clutter, thresh, scheme):
+    """The batched RANSAC in both launch schemes -- rounds of 256 hypotheses (late
+    rounds on the narrow grid, hypotheses beyond the current requirement not
+    generated) and the single pass a call with few pairs takes -- against the
     same samples pushed through the stand-alone kernels one pair at a time:
     P3P -> consensus counts -> sequential replay.  Same device arithmetic, so
     winner, count, iteration trace, pose and mask must agree exactly, for pairs
     that stop in different rounds and an iteration cap that is not a multiple of
     the round size."""
-    from slam_amd import CameraModel, kernels
+    from slam_amd import CameraModel, kernels, _lib
     from slam_amd.backend.tracking.frontend import TrackingFrontend
     from slam_amd.utils.synth import StereoSequence
     cam = CameraModel.kitti_like()
+    _lib.lib.slamhip_tune(4, scheme)
+    try:
+        _rounds_case(cam, kernels, TrackingFrontend, StereoSequence, seed, n_iter, clutter, thresh)
+    finally:
+        _lib.lib.slamhip_tune(4, 0)
+
+
+def _rounds_case(cam, kernels, TrackingFrontend, StereoSequence, seed, n_iter, clutter, thresh):
     seq = StereoSequence(cam, n_frames=7, n_features=900, seed=seed, clutter=clutter, bit_noise=0.05)
     frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(7))]
     frames[3] = tuple(a[:350] for a in frames[3])          # a sparse frame: its pairs behave differently
