@@ -57,3 +57,19 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in src.lower().replace("# no oracle", ""), f
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/slamhip.h is the boundary other hosts bind: it must compile as C99
+    and as C++ on its own (no HIP or torch types)."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use.c"
+    src.write_text('#include "slamhip.h"\nint main(void) { return slamhip_version(); }\n')
+    for cc, flags in (("gcc", ["-std=c99", "-pedantic"]), ("g++", ["-std=c++17", "-x", "c++"])):
+        if shutil.which(cc) is None:
+            continue
+        r = subprocess.run([cc, *flags, "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
+                            "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
