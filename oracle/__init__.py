@@ -1,0 +1,1 @@
+"""CPU restatement of the reference algorithms; test infrastructure only."""

@@ -1,0 +1,1 @@
+"""Hand-over to the back-end: tracking records and loop verification."""

@@ -1,0 +1,1 @@
+"""Loop-closure candidate verification."""

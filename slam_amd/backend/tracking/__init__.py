@@ -1,0 +1,1 @@
+"""Tracking records, feature cache and the tracking-database adaptor."""

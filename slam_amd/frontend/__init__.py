@@ -1,0 +1,1 @@
+"""Front-end: matching, stereo geometry and PnP behind the reference class names."""

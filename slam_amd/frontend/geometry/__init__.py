@@ -1,0 +1,1 @@
+"""Stereo camera model, triangulation and PnP-RANSAC facades."""

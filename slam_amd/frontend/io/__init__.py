@@ -1,0 +1,1 @@
+"""Frame and feature input."""
