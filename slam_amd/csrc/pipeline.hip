@@ -377,12 +377,15 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
 // rounds, which few pairs reach, use one block per 64 hypotheses so that a launch
 // with nothing left to do costs a few thousand empty blocks instead of tens of
 // thousands.
+// MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair.
 constexpr int kWideRounds = 3;
+template <int MODE>
 __global__ __launch_bounds__(64) void ransac_count_kernel(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span, int screened, int slots) {
+    const int32_t *__restrict__ info, int chunks_per_span, int slots) {
+  constexpr bool screened = MODE != 0;
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p = blockIdx.z;
   const size_t row = (size_t)p * slots + blockIdx.y / (kHypPerRound / 64);
@@ -413,11 +416,14 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
     const size_t base = (size_t)obase[p] + p0;
     const int cnt = min(kPtsPerChunk, span1 - p0);
     if (p0 != span0) __syncthreads();
+    Screen32 sc = {0.0f, 0.0f, 0.0f};
     if (screened) {
+      float umax = 0.0f;
       for (int j = threadIdx.x; 2 * j < cnt; j += 64) {
         const size_t a = base + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
-        stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b);
+        stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b, umax);
       }
+      sc = make_screen(h32, wave_max_nonneg(umax), (float)thresh, (float)thr2);
     } else {
       for (int i = threadIdx.x; i < cnt; i += 64) {
         const size_t g = base + i;
@@ -429,9 +435,12 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
       }
     }
     __syncthreads();
-    if (valid)
-      c += screened ? count_chunk_inliers_screened(ldsf, cnt, PL, PR, h32, thresh, thr2)
-                    : count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
+    if (valid) {
+      if (screened)
+        c += count_chunk_inliers_screened<MODE == 2>(ldsf, cnt, PL, PR, h32, sc, thresh, thr2);
+      else
+        c += count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
+    }
   }
   if (valid && c) atomicAdd(slot, c);
 }
@@ -539,6 +548,8 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
   const int rounds = slots > 1 ? 1 : slamhip_ceil_div(prm.n_iter_max, kHypPerRound);
   const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
   const long long pair0 = prm.pair0;
+  const int mode = !slamhip_internal::g_ransac_screen ? 0
+                   : rectified_stereo(prm.cam.K, prm.cam.MR) ? 2 : 1;
   for (int g0 = 0; g0 < n_pairs; g0 += group) {
     const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
     prm.pair0 = pair0 + g0;
@@ -548,11 +559,11 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
-      hipLaunchKernelGGL(ransac_count_kernel,
-                         dim3(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np),
-                         dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh,
-                         rt, counts, info + 8 * (size_t)g0, per_span, slamhip_internal::g_ransac_screen,
-                         slots);
+      const dim3 cgrid(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np);
+      auto count = mode == 2 ? ransac_count_kernel<2> : mode == 1 ? ransac_count_kernel<1>
+                                                                  : ransac_count_kernel<0>;
+      hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
+                         prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots);
     }
     hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds - 1, slots,
                        obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt, counts,

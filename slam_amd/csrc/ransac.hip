@@ -47,21 +47,25 @@ __device__ __forceinline__ void stage_points(double *__restrict__ lds, const PT 
 }
 
 // grid = (hypothesis blocks of 64, point chunks of kPtsPerChunk)
-template <typename PT>
+// MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair
+// (1 and 2 need exact fp32 points).
+template <typename PT, int MODE>
 __global__ __launch_bounds__(64) void ransac_score_kernel(
     const PT *__restrict__ pts, const float *__restrict__ mL, const float *__restrict__ mR, int n,
     const double *__restrict__ Rt, const uint8_t *__restrict__ valid, int h, RansacCam cam,
-    double thr, int32_t *__restrict__ counts, int screened) {
+    double thr, int32_t *__restrict__ counts) {
+  static_assert(MODE == 0 || std::is_same<PT, float>::value, "screening needs fp32 points");
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p0 = blockIdx.y * kPtsPerChunk;
   const int cnt = min(kPtsPerChunk, n - p0);
-  constexpr bool kCanScreen = std::is_same<PT, float>::value;  // exact fp32 points only
-  if (kCanScreen && screened) {
+  float umax = 0.0f;
+  if constexpr (MODE != 0) {
     float *ldsf = reinterpret_cast<float *>(lds);
     for (int j = threadIdx.x; 2 * j < cnt; j += blockDim.x) {
       const size_t a = (size_t)p0 + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
-      stage_pair(ldsf + j * kPairStride, reinterpret_cast<const float *>(pts), mL, mR, a, b);
+      stage_pair(ldsf + j * kPairStride, reinterpret_cast<const float *>(pts), mL, mR, a, b, umax);
     }
+    umax = wave_max_nonneg(umax);
   } else {
     stage_points(lds, pts, mL, mR, p0, cnt);
   }
@@ -77,10 +81,12 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(
   make_projections(Rt + 12 * (size_t)hyp, cam, PL, PR);
   const double thr2 = thr * thr;
   int c;
-  if (kCanScreen && screened) {
+  if constexpr (MODE != 0) {
     Hyp32 h32;
     make_hyp32(PL, PR, h32);
-    c = count_chunk_inliers_screened(reinterpret_cast<const float *>(lds), cnt, PL, PR, h32, thr, thr2);
+    const Screen32 sc = make_screen(h32, umax, (float)thr, (float)thr2);
+    c = count_chunk_inliers_screened<MODE == 2>(reinterpret_cast<const float *>(lds), cnt, PL, PR,
+                                                h32, sc, thr, thr2);
   } else {
     c = count_chunk_inliers(lds, cnt, PL, PR, thr, thr2);
   }
@@ -212,13 +218,16 @@ int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_m
       return SLAMHIP_ELAUNCH;
   }
   const dim3 grid(slamhip_ceil_div(h, 64), chunks), block(64);
-  if (points_fp64)
-    hipLaunchKernelGGL(ransac_score_kernel<double>, grid, block, 0, st, (const double *)d_points,
-                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts, 0);
-  else
-    hipLaunchKernelGGL(ransac_score_kernel<float>, grid, block, 0, st, (const float *)d_points,
-                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts,
-                       slamhip_internal::g_ransac_screen);
+  if (points_fp64) {
+    hipLaunchKernelGGL((ransac_score_kernel<double, 0>), grid, block, 0, st, (const double *)d_points,
+                       d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts);
+  } else {
+    const int mode = !slamhip_internal::g_ransac_screen ? 0 : rectified_stereo(K, M_right) ? 2 : 1;
+    auto kern = mode == 2 ? ransac_score_kernel<float, 2> : mode == 1 ? ransac_score_kernel<float, 1>
+                                                                     : ransac_score_kernel<float, 0>;
+    hipLaunchKernelGGL(kern, grid, block, 0, st, (const float *)d_points, d_meas_l, d_meas_r, n, d_Rt,
+                       d_valid, h, cam, thresh, d_counts);
+  }
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

@@ -94,104 +94,198 @@ __device__ __forceinline__ int count_chunk_inliers(const double *__restrict__ ld
 // closer (or not finite) is re-evaluated by the fp64 path above, so the
 // decisions, and therefore the counts, are exactly those of the fp64 path.
 //
-// Bound (eps = 2^-24; points and pixels are exact fp32 inputs; every fp32
-// operation is rounded once or, if a multiply-add is not fused, twice):
+// Bound (eps = 2^-24; points and pixels are exact fp32 inputs; every product-sum
+// below is an explicit fused multiply-add, rounded once).  With s = |X|+|Y|+|Z| and,
+// per group of rows (xy = rows 0-1, w = row 2, both cameras), A3 = max |entry| of the
+// 3x3 part and At = max |entry| of the last column:
 //   P32 = fl(P):                     |P32 - P| <= eps |P|
-//   x32 = P32 row . [X Y Z 1]:       |x32 - x| <= 8 eps A s,  s = |X|+|Y|+|Z|+1,
-//                                    A = max |entry| of the row (Axy rows 0-1, Aw row 2)
-//   d32 = u*w32 - x32:               |d32 - d| <= D + 2 eps |d32|,
-//                                    D = 8 eps (umax s Aw + s Axy),  umax = max |pixel coordinate|
+//   x32 = fma(P0,X, fma(P1,Y, fma(P2,Z, P3))):
+//                                    |x32 - x| <= 4 eps (A3 s + At) (1 + 2 eps)
+//   rectified pair (below), right x: x32' = fl(x32 - fl(c)) adds eps |c| + eps |x32'|
+//                                    <= eps (A3 s + 3 At)  (|c| <= 2 At), so
+//                                    8 eps (A3 s + At) holds for every projected
+//                                    coordinate; the code uses 8 eps (1.01)
+//   d32 = fma(u, w32, -x32):         |d32 - d| <= D + 2 eps |d32|,   D = s Da + Db,
+//                                    Da = 8 eps (umax A3w + A3xy), Db = 8 eps (umax Atw + Atxy),
+//                                    umax = max |pixel coordinate|
 //   lhs = dx^2 + dy^2:               |lhs32 - lhs| <= 2 a D + 4 D^2 + 8 eps lhs32,  a = |dx32|+|dy32|
 //   rhs = thr^2 w^2:                 |rhs32 - rhs| <= thr^2 (2 |w32| dw + dw^2) + 8 eps rhs32,
-//                                    dw = 8 eps Aw s
-// The cross terms are split with 2xy <= k x^2 + y^2/k (k = 2^-10; a <= sqrt(2 lhs)):
-//   2 a D <= 2k lhs + D^2/k,   2 |w| dw <= k w^2 + dw^2/k,   hence
-//   E = (2k + 8 eps)(lhs32 + rhs32) + (1/k + 4) D^2 + thr^2 (1 + 1/k) dw^2,
-// i.e. one multiply-add per camera on top of a per-(hypothesis, point) constant,
-// with no absolute values.  D and dw are evaluated with their constants doubled,
-// which also covers the rounding of E itself.  The relative part keeps E above
-// 2e-3 of either side, far outside the 1e-10 band in which the fp64 path falls
-// back to the literal formula; in pixels the undecided band is about a thousandth
-// of the threshold.
+//                                    dw = s dwa + dwb,  dwa = 8 eps A3w,  dwb = 8 eps Atw
+// The cross terms are split with 2xy <= k x^2 + y^2/k for any k > 0 (a <= sqrt(2 lhs)),
+//   2 a D <= 2k lhs + D^2/k,   2 |w| dw <= k w^2 + dw^2/k,
+// and the squares with (s p + q)^2 <= 2 s^2 p^2 + 2 q^2, hence
+//   E = (2k + 16 eps)(lhs32 + rhs32) + s^2 Ca + Cb,
+//   Ca = 2 (1/k + 4) Da^2 + 2 thr^2 (1 + 1/k) dwa^2,  Cb = the same of Db and dwb.
+// Ca and Cb belong to the hypothesis (umax is the maximum over the staged chunk) and
+// s^2 to the point, staged rounded up next to it: the bound costs one multiply-add
+// for both cameras and one per camera, with no absolute values.  Keeping the last
+// column apart matters for hypotheses far from the scene (|t| >> s), which random
+// minimal samples produce all the time: there x is about P3 and its rounding error
+// about eps |P3|, not eps |P3| s.  k is chosen per hypothesis,
+// k ~ (Da + Db) / (thr (A3w + Atw)), which balances the two parts of E for a point at
+// the threshold; any k keeps the bound valid.  With KITTI numbers the undecided band
+// is about 0.2 % of the threshold, far outside the 1e-10 band in which the fp64 path
+// falls back to the literal formula.  Results that underflow in fp32 carry an absolute
+// error below 2^-126 times the operand they are multiplied with; Cb has a floor of
+// 1e-30 for them, and strict comparisons leave diff = E = 0 undecided.
+//
+// Rectified pair: when the right camera is the left one shifted along x
+// (M_right = [I | (tx, 0, 0)]) and K is upper triangular, make_projections gives
+// P_right equal to P_left in every entry but [3] (products with the exact 0 and 1
+// entries are exact), so y and w are shared by both cameras and the right x is the
+// left x minus c = P_left[3] - P_right[3]: 7 packed operations for the second camera
+// instead of 16.  The host decides this from K and M_right (rectified_stereo()).
+// A P_right[3] that is not finite (overflow of t_x + tx) makes the right x not
+// finite, which leaves the point undecided; the fp64 path then uses the real last
+// column of P_right.
 // ---------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kPairStride = 18;  // floats per staged pair: X Y Z uL vL uR vR s m, two lanes each
+constexpr int kPairStride = 16;  // floats per staged pair: X Y Z uL vL uR vR s^2 (s = |X|+|Y|+|Z|), two lanes each
 constexpr float kEps32 = 5.9604645e-8f;
-constexpr float kAbsErr = 2.0f * 8.0f * kEps32 * 1.01f;   // doubled 8 eps
-constexpr float kSplit = 1.0f / 1024.0f;                  // k of the cross-term split
-constexpr float kRelErr = 2.0f * kSplit + 2.0f * 8.0f * kEps32 * 1.01f;
+constexpr float kAbsErr = 8.0f * kEps32 * 1.01f;
+constexpr float kRelEps = 16.0f * kEps32 * 1.01f;
+
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
 
 struct Hyp32 {
   float PL[12], PR[12];
-  float Axy, Aw;
+  float A3xy, Atxy, A3w, Atw;  // max |entry|: 3x3 part / last column of rows 0-1 / row 2
+  float cR;                    // P_left[3] - P_right[3] (rectified pair)
 };
 
+// Per hypothesis and staged chunk: the factors of the bound E.
+struct Screen32 {
+  float rel;     // 2k + 16 eps
+  float ca, cb;  // Ca, Cb
+};
+
+// True when P_right differs from P_left in entry [3] only (see above).
+static inline bool rectified_stereo(const double *K, const double *MR) {
+  static const double I34[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+  for (int i = 0; i < 12; ++i)
+    if (i != 3 && MR[i] != I34[i]) return false;
+  return K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0;
+}
+
 __device__ __forceinline__ void make_hyp32(const double (&PL)[12], const double (&PR)[12], Hyp32 &h) {
-  double axy = 0.0, aw = 0.0;
+  double a3xy = 0.0, atxy = 0.0, a3w = 0.0, atw = 0.0;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     h.PL[i] = (float)PL[i];
     h.PR[i] = (float)PR[i];
     const double m = fmax(fabs(PL[i]), fabs(PR[i]));
-    if (i < 8) axy = fmax(axy, m); else aw = fmax(aw, m);
+    if (i < 8) {
+      if ((i & 3) == 3) atxy = fmax(atxy, m); else a3xy = fmax(a3xy, m);
+    } else {
+      if (i == 11) atw = m; else a3w = fmax(a3w, m);
+    }
   }
-  h.Axy = (float)(axy * 1.000001);   // rounded up
-  h.Aw = (float)(aw * 1.000001);
+  h.A3xy = (float)(a3xy * 1.000001);   // rounded up
+  h.Atxy = (float)(atxy * 1.000001);
+  h.A3w = (float)(a3w * 1.000001);
+  h.Atw = (float)(atw * 1.000001);
+  h.cR = (float)(PL[3] - PR[3]);
 }
 
 // Writes the staged record of the point pair (a, b) (b = a when the chunk has an
-// odd point count; the caller ignores that second lane).
+// odd point count; the caller ignores that second lane) and raises umax to the
+// largest |pixel coordinate| of the pair.  fmaxf drops a NaN coordinate; the point
+// that has it is undecided in that camera whatever the bound, and the bound of the
+// other points does not depend on it.
 __device__ __forceinline__ void stage_pair(float *__restrict__ o, const float *__restrict__ X,
                                            const float *__restrict__ mL,
-                                           const float *__restrict__ mR, size_t a, size_t b) {
+                                           const float *__restrict__ mR, size_t a, size_t b,
+                                           float &umax) {
   const size_t idx[2] = {a, b};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const size_t g = idx[k];
     const float x = X[3 * g], y = X[3 * g + 1], z = X[3 * g + 2];
     const float ul = mL[2 * g], vl = mL[2 * g + 1], ur = mR[2 * g], vr = mR[2 * g + 1];
-    const float s = (fabsf(x) + fabsf(y) + fabsf(z) + 1.0f) * 1.000001f;
+    const float s = (fabsf(x) + fabsf(y) + fabsf(z)) * 1.000001f;
     const float um = fmaxf(fmaxf(fabsf(ul), fabsf(vl)), fmaxf(fabsf(ur), fabsf(vr)));
     o[0 + k] = x; o[2 + k] = y; o[4 + k] = z;
     o[6 + k] = ul; o[8 + k] = vl; o[10 + k] = ur; o[12 + k] = vr;
-    o[14 + k] = s; o[16 + k] = um * s * 1.000001f;
+    o[14 + k] = (s * s) * 1.000001f;
+    umax = fmaxf(umax, um);
   }
 }
 
-// diff = lhs - rhs and sum = lhs + rhs for one camera and a pair of points
-__device__ __forceinline__ void screen_camera(const float (&P)[12], f2 X, f2 Y, f2 Z, f2 u, f2 v,
-                                              float thr2f, f2 &diff, f2 &sum) {
-  const f2 x = P[0] * X + (P[1] * Y + (P[2] * Z + P[3]));
-  const f2 y = P[4] * X + (P[5] * Y + (P[6] * Z + P[7]));
-  const f2 w = P[8] * X + (P[9] * Y + (P[10] * Z + P[11]));
-  const f2 dx = u * w - x;
-  const f2 dy = v * w - y;
-  const f2 lhs = dx * dx + dy * dy;
-  const f2 rhs = thr2f * (w * w);
-  diff = lhs - rhs;
-  sum = lhs + rhs;
+// Maximum over the 64 lanes of a one-wavefront block of a value that is not
+// negative or NaN: the bit patterns of such floats order like unsigned integers.  Rows of 16 lanes reduce through DPP, the four rows through
+// scalar registers.
+__device__ __forceinline__ float wave_max_nonneg(float f) {
+  unsigned v = __float_as_uint(f);
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // lanes 1,0,3,2
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // lanes 2,3,0,1
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // half-row mirror
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row mirror
+  const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+  const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+  return __uint_as_float(max(max(r0, r1), max(r2, r3)));
+}
+
+__device__ __forceinline__ Screen32 make_screen(const Hyp32 &h, float umax, float thr, float thr2f) {
+  const float Da = kAbsErr * (umax * h.A3w + h.A3xy) * 1.000001f;
+  const float Db = kAbsErr * (umax * h.Atw + h.Atxy) * 1.000001f;
+  const float dwa = kAbsErr * h.A3w, dwb = kAbsErr * h.Atw;
+  // any positive k is valid; the clamp also keeps it positive when a factor is not finite
+  const float k = fminf(fmaxf(0.75f * (Da + Db) / (thr * (h.A3w + h.Atw)), 9.5367432e-7f), 0.0625f);
+  const float ik = 1.0f / k * 1.000001f;
+  const float g1 = 2.0f * (ik + 4.0f), g2 = 2.0f * thr2f * 1.01f * (1.0f + ik);
+  Screen32 sc;
+  sc.rel = (2.0f * k + kRelEps) * 1.000001f;
+  sc.ca = (g1 * (Da * Da) + g2 * (dwa * dwa)) * 1.00001f;
+  sc.cb = (g1 * (Db * Db) + g2 * (dwb * dwb)) * 1.00001f + 1e-30f;   // floor: see underflow above
+  return sc;
 }
 
 // Inliers (both cameras) among `cnt` points staged as pairs (stage_pair).
+template <bool RECT>
 __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restrict__ lds, int cnt,
                                                             const double (&PL)[12],
                                                             const double (&PR)[12], const Hyp32 &h,
-                                                            double thr, double thr2) {
-  const float thr2f = (float)thr2;
-  const float thr2up = thr2f * 1.01f;
+                                                            Screen32 sc, double thr, double thr2) {
+  const f2 thr2f = splat((float)thr2), nthr2f = -thr2f;
+  const f2 rel = splat(sc.rel);
   int c = 0;
   const int pairs = (cnt + 1) >> 1;
   for (int j = 0; j < pairs; ++j) {
     const f2 *q = reinterpret_cast<const f2 *>(lds + j * kPairStride);
-    const f2 X = q[0], Y = q[1], Z = q[2], s = q[7], m = q[8];
-    const f2 dw = (kAbsErr * h.Aw) * s;
-    const f2 D = kAbsErr * (m * h.Aw + s * h.Axy);
-    const f2 C = (1.0f / kSplit + 4.0f) * (D * D) + (thr2up * (1.0f + 1.0f / kSplit)) * (dw * dw);
+    const f2 X = q[0], Y = q[1], Z = q[2];
+    const f2 C = fma2(q[7], splat(sc.ca), splat(sc.cb));
+    // diff = lhs - rhs and sum = lhs + rhs per camera
     f2 dL, sL, dR, sR;
-    screen_camera(h.PL, X, Y, Z, q[3], q[4], thr2f, dL, sL);
-    screen_camera(h.PR, X, Y, Z, q[5], q[6], thr2f, dR, sR);
-    const f2 eL = kRelErr * sL + C, eR = kRelErr * sR + C;
+    {
+      const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
+      const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
+      const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
+      const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
+      const f2 lhs = fma2(dx, dx, dy * dy);
+      const f2 w2 = w * w;
+      dL = fma2(nthr2f, w2, lhs);
+      sL = fma2(thr2f, w2, lhs);
+      if (RECT) {
+        const f2 xr = x - h.cR;
+        const f2 dxr = fma2(q[5], w, -xr), dyr = fma2(q[6], w, -y);
+        const f2 lhsr = fma2(dxr, dxr, dyr * dyr);
+        dR = fma2(nthr2f, w2, lhsr);
+        sR = fma2(thr2f, w2, lhsr);
+      }
+    }
+    if (!RECT) {
+      const f2 x = fma2(splat(h.PR[0]), X, fma2(splat(h.PR[1]), Y, fma2(splat(h.PR[2]), Z, splat(h.PR[3]))));
+      const f2 y = fma2(splat(h.PR[4]), X, fma2(splat(h.PR[5]), Y, fma2(splat(h.PR[6]), Z, splat(h.PR[7]))));
+      const f2 w = fma2(splat(h.PR[8]), X, fma2(splat(h.PR[9]), Y, fma2(splat(h.PR[10]), Z, splat(h.PR[11]))));
+      const f2 dx = fma2(q[5], w, -x), dy = fma2(q[6], w, -y);
+      const f2 lhs = fma2(dx, dx, dy * dy);
+      const f2 w2 = w * w;
+      dR = fma2(nthr2f, w2, lhs);
+      sR = fma2(thr2f, w2, lhs);
+    }
+    const f2 eL = fma2(rel, sL, C), eR = fma2(rel, sR, C);
     const bool has1 = 2 * j + 1 < cnt;
     // NaN or infinity on either side makes `sure` false: the fp64 path decides
     const bool outL0 = dL.x > eL.x, outR0 = dR.x > eR.x, outL1 = dL.y > eL.y, outR1 = dR.y > eR.y;
@@ -205,8 +299,16 @@ __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restr
         if (k == 0 ? ok0 : ok1) continue;
         const float *f = lds + j * kPairStride + k;
         const double Xd = (double)f[0], Yd = (double)f[2], Zd = (double)f[4];
-        const bool in = inlier_one_camera(PL, Xd, Yd, Zd, (double)f[6], (double)f[8], thr, thr2) &&
-                        inlier_one_camera(PR, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
+        bool in = inlier_one_camera(PL, Xd, Yd, Zd, (double)f[6], (double)f[8], thr, thr2);
+        if (RECT) {
+          // the 3x3 part of P_right is that of P_left bit for bit: only its last column
+          // stays live through the loop
+          const double Pr[12] = {PL[0], PL[1], PL[2],  PR[3], PL[4], PL[5],
+                                 PL[6], PR[7], PL[8], PL[9], PL[10], PR[11]};
+          in = in && inlier_one_camera(Pr, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
+        } else {
+          in = in && inlier_one_camera(PR, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
+        }
         if (k == 0) in0 = in; else in1 = in;
       }
     }

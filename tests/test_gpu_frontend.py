@@ -218,6 +218,13 @@ def test_ransac_rounds_equal_stand_alone_kernels(seed, n_iter, clutter, thresh, 
     from slam_amd.backend.tracking.frontend import TrackingFrontend
     from slam_amd.utils.synth import StereoSequence
     cam = CameraModel.kitti_like()
+    if seed == 5:
+        # a right camera that is not exactly the left one shifted along x: the counting
+        # kernels then project through both matrices instead of sharing y and w
+        MR = cam.M_right.copy()
+        a = 1e-4
+        MR[:, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        cam = CameraModel(cam.K, cam.M_left, MR)
     _lib.lib.slamhip_tune(4, scheme)
     try:
         _rounds_case(cam, kernels, TrackingFrontend, StereoSequence, seed, n_iter, clutter, thresh)

@@ -147,16 +147,39 @@ def test_pnp_facade_with_injected_hypotheses():
                                                         so.project(X, cam.K @ Rt_R), 4.0))
 
 
-def test_packed_fp32_screening_never_changes_a_count():
+def _screen_camera(kind):
+    """Camera pairs that take the different screening kernels: a rectified pair
+    (right camera = left shifted along x) shares y and w between the cameras; a skewed
+    K still does; a rotated right camera or a K with entries below the diagonal do not."""
+    from slam_amd import CameraModel
+    cam = CameraModel.kitti_like()
+    K, MR = cam.K.copy(), cam.M_right.copy()
+    if kind == "skewed_k":
+        K[0, 1] = 0.37
+    elif kind == "rotated_right":
+        a = 2e-3
+        MR[:, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        MR[1, 3] = 0.004
+    elif kind == "lower_k":
+        K[1, 0] = 0.02
+        K[2, 0] = 1e-6
+    elif kind == "wide_baseline":
+        MR[0, 3] = -350.0           # c = fx * tx far above every other entry of P
+    return CameraModel(K, cam.M_left, MR)
+
+
+@pytest.mark.parametrize("kind", ["rectified", "skewed_k", "rotated_right", "lower_k", "wide_baseline"])
+def test_packed_fp32_screening_never_changes_a_count(kind):
     """The counting kernels screen in packed fp32 and hand every undecided point
     to the fp64 path; with the screen switched off (tune knob 2) the same calls must
     return identical counts.  The scene is built to stress the bound: measurements
     placed exactly on, and a few ulps either side of, the threshold circle of the
     true pose; near (2 m) and far (400 m) points; points behind the camera and at
-    w ~ 0; hypotheses from exact to wild, including NaN."""
-    from slam_amd import kernels, CameraModel, _lib
+    w ~ 0; hypotheses from exact to wild, including NaN, infinity and a translation
+    whose projection overflows fp64."""
+    from slam_amd import kernels, _lib
     from slam_amd.utils.synth import perturbed_hypotheses
-    cam = CameraModel.kitti_like()
+    cam = _screen_camera(kind)
     rng = np.random.default_rng(21)
     n, H, thr = 3001, 6000, 2.0
     X = np.column_stack([rng.uniform(-40, 40, n), rng.uniform(-5, 5, n), rng.uniform(2, 400, n)])
@@ -177,7 +200,9 @@ def test_packed_fp32_screening_never_changes_a_count():
     Rts[1, 2, 3] = 0.0                              # t_z = 0: w ~ Z
     Rts[2] = np.nan
     Rts[3] *= 1e6                                   # overflows fp32 squares
-    valid[:4] = 1
+    Rts[4, 0, 3] = -1.7e308                         # fx * t_x overflows fp64
+    Rts[5, 0, 3] = np.inf
+    valid[:6] = 1
     try:
         assert _lib.lib.slamhip_tune(2, 0) == 0
         ref = kernels.ransac_score(X, mL, mR, Rts, valid, cam.K, cam.M_right, thr).cpu().numpy()
