@@ -380,10 +380,10 @@ __global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
 // MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair.
 constexpr int kWideRounds = 3;
 template <int MODE>
-__global__ __launch_bounds__(64) void ransac_count_kernel(
+__device__ __forceinline__ void ransac_count_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
-    RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
+    const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
     const int32_t *__restrict__ info, int chunks_per_span, int slots) {
   constexpr bool screened = MODE != 0;
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
   }
   Hyp32 h32;
   if (screened) make_hyp32(PL, PR, h32);
-  const double thr2 = thresh * thresh;
+  const double thr2 = threshold_squared(thresh);
   float *ldsf = reinterpret_cast<float *>(lds);
   int c = 0;
   for (int p0 = span0; p0 < span1; p0 += kPtsPerChunk) {
@@ -418,12 +418,12 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
     if (p0 != span0) __syncthreads();
     Screen32 sc = {0.0f, 0.0f, 0.0f};
     if (screened) {
-      float umax = 0.0f;
+      unsigned umax = 0u;
       for (int j = threadIdx.x; 2 * j < cnt; j += 64) {
         const size_t a = base + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
         stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b, umax);
       }
-      sc = make_screen(h32, wave_max_nonneg(umax), (float)thresh, (float)thr2);
+      sc = make_screen(h32, wave_max_u32(umax), (float)thresh, (float)thr2);
     } else {
       for (int i = threadIdx.x; i < cnt; i += 64) {
         const size_t g = base + i;
@@ -443,6 +443,27 @@ __global__ __launch_bounds__(64) void ransac_count_kernel(
     }
   }
   if (valid && c) atomicAdd(slot, c);
+}
+
+#define SLAMHIP_COUNT_ARGS                                                                         \
+  const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,                         \
+      const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,  \
+      RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,   \
+      const int32_t *__restrict__ info, int chunks_per_span, int slots
+#define SLAMHIP_COUNT_PASS obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, chunks_per_span, slots
+
+__global__ __launch_bounds__(64) void ransac_count_fp64_kernel(SLAMHIP_COUNT_ARGS) {
+  ransac_count_body<0>(SLAMHIP_COUNT_PASS);
+}
+__global__ __launch_bounds__(64) void ransac_count_screened_kernel(SLAMHIP_COUNT_ARGS) {
+  ransac_count_body<1>(SLAMHIP_COUNT_PASS);
+}
+// The rectified-pair loop needs a few registers less than the rare fp64 branch inside
+// it; capping the kernel at a quarter of the register file (four wavefronts per SIMD)
+// moves those few out of the loop's way.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ransac_count_rectified_kernel(SLAMHIP_COUNT_ARGS) {
+  ransac_count_body<2>(SLAMHIP_COUNT_PASS);
 }
 
 // Replays the hypothesis blocks not replayed yet (the last round's one, or all
@@ -486,7 +507,7 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
   double Rt[12], PL[12], PR[12];
   for (int i = 0; i < 12; ++i) Rt[i] = best_rt[i];
   make_projections(Rt, prm.cam, PL, PR);
-  const double thr2 = prm.thresh * prm.thresh;
+  const double thr2 = threshold_squared(prm.thresh);
   const bool have = sh[1] != 0;
   for (int i = threadIdx.x; i < n; i += kBlock) {
     bool in = false;
@@ -548,8 +569,7 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
   const int rounds = slots > 1 ? 1 : slamhip_ceil_div(prm.n_iter_max, kHypPerRound);
   const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
   const long long pair0 = prm.pair0;
-  const int mode = !slamhip_internal::g_ransac_screen ? 0
-                   : rectified_stereo(prm.cam.K, prm.cam.MR) ? 2 : 1;
+  const int mode = screening_mode(slamhip_internal::g_ransac_screen, prm.cam.K, prm.cam.MR, prm.thresh);
   for (int g0 = 0; g0 < n_pairs; g0 += group) {
     const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
     prm.pair0 = pair0 + g0;
@@ -560,8 +580,8 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
       const dim3 cgrid(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np);
-      auto count = mode == 2 ? ransac_count_kernel<2> : mode == 1 ? ransac_count_kernel<1>
-                                                                  : ransac_count_kernel<0>;
+      auto count = mode == 2 ? ransac_count_rectified_kernel
+                   : mode == 1 ? ransac_count_screened_kernel : ransac_count_fp64_kernel;
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
                          prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots);
     }

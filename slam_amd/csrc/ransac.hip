@@ -58,14 +58,14 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p0 = blockIdx.y * kPtsPerChunk;
   const int cnt = min(kPtsPerChunk, n - p0);
-  float umax = 0.0f;
+  unsigned umax = 0u;
   if constexpr (MODE != 0) {
     float *ldsf = reinterpret_cast<float *>(lds);
     for (int j = threadIdx.x; 2 * j < cnt; j += blockDim.x) {
       const size_t a = (size_t)p0 + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
       stage_pair(ldsf + j * kPairStride, reinterpret_cast<const float *>(pts), mL, mR, a, b, umax);
     }
-    umax = wave_max_nonneg(umax);
+    umax = wave_max_u32(umax);
   } else {
     stage_points(lds, pts, mL, mR, p0, cnt);
   }
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(
   }
   double PL[12], PR[12];
   make_projections(Rt + 12 * (size_t)hyp, cam, PL, PR);
-  const double thr2 = thr * thr;
+  const double thr2 = threshold_squared(thr);
   int c;
   if constexpr (MODE != 0) {
     Hyp32 h32;
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void ransac_mask_kernel(
   const double X = (double)pts[3 * (size_t)p + 0];
   const double Y = (double)pts[3 * (size_t)p + 1];
   const double Z = (double)pts[3 * (size_t)p + 2];
-  const double thr2 = thr * thr;
+  const double thr2 = threshold_squared(thr);
   const bool inL = inlier_one_camera(PL, X, Y, Z, (double)mL[2 * (size_t)p + 0],
                                      (double)mL[2 * (size_t)p + 1], thr, thr2);
   const bool inR = inlier_one_camera(PR, X, Y, Z, (double)mR[2 * (size_t)p + 0],
@@ -222,7 +222,7 @@ int slamhip_ransac_score(const void *d_points, int points_fp64, const float *d_m
     hipLaunchKernelGGL((ransac_score_kernel<double, 0>), grid, block, 0, st, (const double *)d_points,
                        d_meas_l, d_meas_r, n, d_Rt, d_valid, h, cam, thresh, d_counts);
   } else {
-    const int mode = !slamhip_internal::g_ransac_screen ? 0 : rectified_stereo(K, M_right) ? 2 : 1;
+    const int mode = screening_mode(slamhip_internal::g_ransac_screen, K, M_right, thresh);
     auto kern = mode == 2 ? ransac_score_kernel<float, 2> : mode == 1 ? ransac_score_kernel<float, 1>
                                                                      : ransac_score_kernel<float, 0>;
     hipLaunchKernelGGL(kern, grid, block, 0, st, (const float *)d_points, d_meas_l, d_meas_r, n, d_Rt,

@@ -45,6 +45,10 @@ __device__ __forceinline__ void make_projections(const double *__restrict__ Rt,
     }
 }
 
+// thr^2 for the squared form of `error <= thr`; a negative or NaN threshold accepts
+// nothing in the reference (pnp.py:86-91), and so does lhs <= -w^2.
+__device__ __forceinline__ double threshold_squared(double thr) { return thr >= 0.0 ? thr * thr : -1.0; }
+
 // Literal reference sequence for one camera (used for borderline points only).
 __device__ __forceinline__ bool inlier_exact(double x, double y, double w, double mu, double mv,
                                           double thr) {
@@ -114,30 +118,38 @@ __device__ __forceinline__ int count_chunk_inliers(const double *__restrict__ ld
 // The cross terms are split with 2xy <= k x^2 + y^2/k for any k > 0 (a <= sqrt(2 lhs)),
 //   2 a D <= 2k lhs + D^2/k,   2 |w| dw <= k w^2 + dw^2/k,
 // and the squares with (s p + q)^2 <= 2 s^2 p^2 + 2 q^2, hence
-//   E = (2k + 16 eps)(lhs32 + rhs32) + s^2 Ca + Cb,
+//   E = r (lhs32 + rhs32) + s^2 Ca + Cb,   r = 2k + 16 eps,
 //   Ca = 2 (1/k + 4) Da^2 + 2 thr^2 (1 + 1/k) dwa^2,  Cb = the same of Db and dwb.
-// Ca and Cb belong to the hypothesis (umax is the maximum over the staged chunk) and
-// s^2 to the point, staged rounded up next to it: the bound costs one multiply-add
-// for both cameras and one per camera, with no absolute values.  Keeping the last
-// column apart matters for hypotheses far from the scene (|t| >> s), which random
-// minimal samples produce all the time: there x is about P3 and its rounding error
-// about eps |P3|, not eps |P3| s.  k is chosen per hypothesis,
+// With lhs32 + rhs32 = 2 rhs32 + diff32, diff32 > E is diff32 (1 - r) > 2 r rhs32 + C
+// and diff32 < -E is diff32 (1 + r) < -(2 r rhs32 + C), so one threshold serves both:
+//   T = (2 r thr^2 w32^2 + s^2 Ca + Cb) / (1 - r):   diff32 > T  => outside for sure,
+//                                                    diff32 < -T => inside for sure.
+// Ca, Cb and r belong to the hypothesis (umax is the maximum over the staged chunk)
+// and s^2 to the point, staged rounded up next to it: T costs two multiply-adds per
+// camera, and only two in all when the cameras share w (below), with no absolute
+// values.  Keeping the last column apart matters for hypotheses far from the scene
+// (|t| >> s), which random minimal samples produce all the time: there x is about P3
+// and its rounding error about eps |P3|, not eps |P3| s.  k is chosen per hypothesis,
 // k ~ (Da + Db) / (thr (A3w + Atw)), which balances the two parts of E for a point at
 // the threshold; any k keeps the bound valid.  With KITTI numbers the undecided band
 // is about 0.2 % of the threshold, far outside the 1e-10 band in which the fp64 path
-// falls back to the literal formula.  Results that underflow in fp32 carry an absolute
-// error below 2^-126 times the operand they are multiplied with; Cb has a floor of
-// 1e-30 for them, and strict comparisons leave diff = E = 0 undecided.
+// falls back to the literal formula.
+//
+// Domain.  The bound assumes that nothing overflows, so screening is confined to
+// sum |P entries| <= 1e9, s <= 1e4, umax <= 1e5 and thr <= 1e3 (then lhs, rhs < 1e37);
+// outside, or with anything not finite, T is made NaN or infinite (Ca for a
+// hypothesis or a chunk, s^2 for a point), no comparison with it holds and the fp64
+// path decides.  Results that underflow in fp32 carry an absolute error below 2^-126
+// times the operand they are multiplied with; Cb has a floor of 1e-30 for them, and
+// strict comparisons leave diff = T = 0 undecided.
 //
 // Rectified pair: when the right camera is the left one shifted along x
 // (M_right = [I | (tx, 0, 0)]) and K is upper triangular, make_projections gives
 // P_right equal to P_left in every entry but [3] (products with the exact 0 and 1
 // entries are exact), so y and w are shared by both cameras and the right x is the
 // left x minus c = P_left[3] - P_right[3]: 7 packed operations for the second camera
-// instead of 16.  The host decides this from K and M_right (rectified_stereo()).
-// A P_right[3] that is not finite (overflow of t_x + tx) makes the right x not
-// finite, which leaves the point undecided; the fp64 path then uses the real last
-// column of P_right.
+// instead of 16, and one threshold T for both.  The host decides this from K and
+// M_right (rectified_stereo()).  The fp64 path uses the real last column of P_right.
 // ---------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
 
@@ -145,6 +157,10 @@ constexpr int kPairStride = 16;  // floats per staged pair: X Y Z uL vL uR vR s^
 constexpr float kEps32 = 5.9604645e-8f;
 constexpr float kAbsErr = 8.0f * kEps32 * 1.01f;
 constexpr float kRelEps = 16.0f * kEps32 * 1.01f;
+constexpr double kScreenMaxThr = 1e3;   // screening domain (see above)
+constexpr double kScreenMaxP = 1e9;
+constexpr float kScreenMaxS = 1e4f;
+constexpr float kScreenMaxPix = 1e5f;
 
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
@@ -155,10 +171,9 @@ struct Hyp32 {
   float cR;                    // P_left[3] - P_right[3] (rectified pair)
 };
 
-// Per hypothesis and staged chunk: the factors of the bound E.
+// Per hypothesis and staged chunk: T = aT w^2 + s^2 ca + cb.
 struct Screen32 {
-  float rel;     // 2k + 16 eps
-  float ca, cb;  // Ca, Cb
+  float aT, ca, cb;
 };
 
 // True when P_right differs from P_left in entry [3] only (see above).
@@ -169,20 +184,27 @@ static inline bool rectified_stereo(const double *K, const double *MR) {
   return K[3] == 0.0 && K[6] == 0.0 && K[7] == 0.0;
 }
 
+// 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair.
+static inline int screening_mode(int enabled, const double *K, const double *MR, double thr) {
+  if (!enabled || !(thr >= 0.0 && thr <= kScreenMaxThr)) return 0;
+  return rectified_stereo(K, MR) ? 2 : 1;
+}
+
 __device__ __forceinline__ void make_hyp32(const double (&PL)[12], const double (&PR)[12], Hyp32 &h) {
-  double a3xy = 0.0, atxy = 0.0, a3w = 0.0, atw = 0.0;
+  double a3xy = 0.0, atxy = 0.0, a3w = 0.0, atw = 0.0, total = 0.0;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
     h.PL[i] = (float)PL[i];
     h.PR[i] = (float)PR[i];
     const double m = fmax(fabs(PL[i]), fabs(PR[i]));
+    total += fabs(PL[i]) + fabs(PR[i]);   // NaN or infinite if any entry is
     if (i < 8) {
       if ((i & 3) == 3) atxy = fmax(atxy, m); else a3xy = fmax(a3xy, m);
     } else {
       if (i == 11) atw = m; else a3w = fmax(a3w, m);
     }
   }
-  h.A3xy = (float)(a3xy * 1.000001);   // rounded up
+  h.A3xy = (total <= kScreenMaxP) ? (float)(a3xy * 1.000001) : __builtin_nanf("");   // rounded up
   h.Atxy = (float)(atxy * 1.000001);
   h.A3w = (float)(a3w * 1.000001);
   h.Atw = (float)(atw * 1.000001);
@@ -190,14 +212,13 @@ __device__ __forceinline__ void make_hyp32(const double (&PL)[12], const double 
 }
 
 // Writes the staged record of the point pair (a, b) (b = a when the chunk has an
-// odd point count; the caller ignores that second lane) and raises umax to the
-// largest |pixel coordinate| of the pair.  fmaxf drops a NaN coordinate; the point
-// that has it is undecided in that camera whatever the bound, and the bound of the
-// other points does not depend on it.
+// odd point count; the caller ignores that second lane) and raises umax_bits to the
+// bit pattern of the largest |pixel coordinate| of the pair; a NaN coordinate has
+// the largest pattern of all and stays.
 __device__ __forceinline__ void stage_pair(float *__restrict__ o, const float *__restrict__ X,
                                            const float *__restrict__ mL,
                                            const float *__restrict__ mR, size_t a, size_t b,
-                                           float &umax) {
+                                           unsigned &umax_bits) {
   const size_t idx[2] = {a, b};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -205,29 +226,30 @@ __device__ __forceinline__ void stage_pair(float *__restrict__ o, const float *_
     const float x = X[3 * g], y = X[3 * g + 1], z = X[3 * g + 2];
     const float ul = mL[2 * g], vl = mL[2 * g + 1], ur = mR[2 * g], vr = mR[2 * g + 1];
     const float s = (fabsf(x) + fabsf(y) + fabsf(z)) * 1.000001f;
-    const float um = fmaxf(fmaxf(fabsf(ul), fabsf(vl)), fmaxf(fabsf(ur), fabsf(vr)));
     o[0 + k] = x; o[2 + k] = y; o[4 + k] = z;
     o[6 + k] = ul; o[8 + k] = vl; o[10 + k] = ur; o[12 + k] = vr;
-    o[14 + k] = (s * s) * 1.000001f;
-    umax = fmaxf(umax, um);
+    o[14 + k] = (s <= kScreenMaxS) ? (s * s) * 1.000001f : __builtin_inff();   // NaN lands here too
+    umax_bits = max(max(umax_bits, __float_as_uint(fabsf(ul))), __float_as_uint(fabsf(vl)));
+    umax_bits = max(max(umax_bits, __float_as_uint(fabsf(ur))), __float_as_uint(fabsf(vr)));
   }
 }
 
-// Maximum over the 64 lanes of a one-wavefront block of a value that is not
-// negative or NaN: the bit patterns of such floats order like unsigned integers.  Rows of 16 lanes reduce through DPP, the four rows through
-// scalar registers.
-__device__ __forceinline__ float wave_max_nonneg(float f) {
-  unsigned v = __float_as_uint(f);
+// Maximum over the 64 lanes of a one-wavefront block.  Rows of 16 lanes reduce
+// through DPP, the four rows through scalar registers.  Bit patterns of floats
+// that are not negative order like the floats, with NaN above infinity.
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));   // lanes 1,0,3,2
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));   // lanes 2,3,0,1
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));  // half-row mirror
   v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));  // row mirror
   const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
   const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
-  return __uint_as_float(max(max(r0, r1), max(r2, r3)));
+  return max(max(r0, r1), max(r2, r3));
 }
 
-__device__ __forceinline__ Screen32 make_screen(const Hyp32 &h, float umax, float thr, float thr2f) {
+// thr in [0, kScreenMaxThr]; umax_bits from stage_pair / wave_max_u32.
+__device__ __forceinline__ Screen32 make_screen(const Hyp32 &h, unsigned umax_bits, float thr, float thr2f) {
+  const float umax = __uint_as_float(umax_bits);
   const float Da = kAbsErr * (umax * h.A3w + h.A3xy) * 1.000001f;
   const float Db = kAbsErr * (umax * h.Atw + h.Atxy) * 1.000001f;
   const float dwa = kAbsErr * h.A3w, dwb = kAbsErr * h.Atw;
@@ -235,10 +257,13 @@ __device__ __forceinline__ Screen32 make_screen(const Hyp32 &h, float umax, floa
   const float k = fminf(fmaxf(0.75f * (Da + Db) / (thr * (h.A3w + h.Atw)), 9.5367432e-7f), 0.0625f);
   const float ik = 1.0f / k * 1.000001f;
   const float g1 = 2.0f * (ik + 4.0f), g2 = 2.0f * thr2f * 1.01f * (1.0f + ik);
+  const float r = (2.0f * k + kRelEps) * 1.000001f;   // <= 0.126
+  const float inv = 1.00001f / (1.0f - r);
   Screen32 sc;
-  sc.rel = (2.0f * k + kRelEps) * 1.000001f;
-  sc.ca = (g1 * (Da * Da) + g2 * (dwa * dwa)) * 1.00001f;
-  sc.cb = (g1 * (Db * Db) + g2 * (dwb * dwb)) * 1.00001f + 1e-30f;   // floor: see underflow above
+  sc.aT = 2.0f * r * thr2f * 1.000001f * inv;
+  sc.ca = (g1 * (Da * Da) + g2 * (dwa * dwa)) * inv;
+  sc.cb = (g1 * (Db * Db) + g2 * (dwb * dwb)) * inv + 1e-30f;
+  if (!(umax <= kScreenMaxPix)) sc.ca = __builtin_nanf("");
   return sc;
 }
 
@@ -248,51 +273,47 @@ __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restr
                                                             const double (&PL)[12],
                                                             const double (&PR)[12], const Hyp32 &h,
                                                             Screen32 sc, double thr, double thr2) {
-  const f2 thr2f = splat((float)thr2), nthr2f = -thr2f;
-  const f2 rel = splat(sc.rel);
+  // uniform: keep it in scalar registers
+  const f2 nthr2f = splat(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+      __builtin_bit_cast(int, -(float)thr2))));
+  const f2 aT = splat(sc.aT), ca = splat(sc.ca), cb = splat(sc.cb);
   int c = 0;
   const int pairs = (cnt + 1) >> 1;
   for (int j = 0; j < pairs; ++j) {
     const f2 *q = reinterpret_cast<const f2 *>(lds + j * kPairStride);
     const f2 X = q[0], Y = q[1], Z = q[2];
-    const f2 C = fma2(q[7], splat(sc.ca), splat(sc.cb));
-    // diff = lhs - rhs and sum = lhs + rhs per camera
-    f2 dL, sL, dR, sR;
-    {
-      const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
-      const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
-      const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
-      const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
-      const f2 lhs = fma2(dx, dx, dy * dy);
-      const f2 w2 = w * w;
-      dL = fma2(nthr2f, w2, lhs);
-      sL = fma2(thr2f, w2, lhs);
-      if (RECT) {
-        const f2 xr = x - h.cR;
-        const f2 dxr = fma2(q[5], w, -xr), dyr = fma2(q[6], w, -y);
-        const f2 lhsr = fma2(dxr, dxr, dyr * dyr);
-        dR = fma2(nthr2f, w2, lhsr);
-        sR = fma2(thr2f, w2, lhsr);
-      }
+    const f2 C = fma2(q[7], ca, cb);
+    const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
+    const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
+    const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
+    const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
+    const f2 w2 = w * w;
+    const f2 dL = fma2(nthr2f, w2, fma2(dx, dx, dy * dy));   // lhs - rhs, left camera
+    const f2 TL = fma2(aT, w2, C);
+    bool in0, in1, ok0, ok1;
+    if (RECT) {
+      const f2 xr = x - h.cR;
+      const f2 dxr = fma2(q[5], w, -xr), dyr = fma2(q[6], w, -y);
+      const f2 dR = fma2(nthr2f, w2, fma2(dxr, dxr, dyr * dyr));
+      // one threshold for both cameras: the larger diff decides.  fmaxf drops a NaN
+      // operand, but whatever makes one diff NaN makes T NaN or infinite as well
+      const float m0 = fmaxf(dL.x, dR.x), m1 = fmaxf(dL.y, dR.y);
+      in0 = m0 < -TL.x; in1 = m1 < -TL.y;
+      ok0 = in0 || m0 > TL.x; ok1 = in1 || m1 > TL.y;
+    } else {
+      const f2 xr = fma2(splat(h.PR[0]), X, fma2(splat(h.PR[1]), Y, fma2(splat(h.PR[2]), Z, splat(h.PR[3]))));
+      const f2 yr = fma2(splat(h.PR[4]), X, fma2(splat(h.PR[5]), Y, fma2(splat(h.PR[6]), Z, splat(h.PR[7]))));
+      const f2 wr = fma2(splat(h.PR[8]), X, fma2(splat(h.PR[9]), Y, fma2(splat(h.PR[10]), Z, splat(h.PR[11]))));
+      const f2 dxr = fma2(q[5], wr, -xr), dyr = fma2(q[6], wr, -yr);
+      const f2 wr2 = wr * wr;
+      const f2 dR = fma2(nthr2f, wr2, fma2(dxr, dxr, dyr * dyr));
+      const f2 TR = fma2(aT, wr2, C);
+      in0 = dL.x < -TL.x && dR.x < -TR.x; in1 = dL.y < -TL.y && dR.y < -TR.y;
+      // decided: surely inside both cameras, or surely outside one of them
+      ok0 = in0 || dL.x > TL.x || dR.x > TR.x; ok1 = in1 || dL.y > TL.y || dR.y > TR.y;
     }
-    if (!RECT) {
-      const f2 x = fma2(splat(h.PR[0]), X, fma2(splat(h.PR[1]), Y, fma2(splat(h.PR[2]), Z, splat(h.PR[3]))));
-      const f2 y = fma2(splat(h.PR[4]), X, fma2(splat(h.PR[5]), Y, fma2(splat(h.PR[6]), Z, splat(h.PR[7]))));
-      const f2 w = fma2(splat(h.PR[8]), X, fma2(splat(h.PR[9]), Y, fma2(splat(h.PR[10]), Z, splat(h.PR[11]))));
-      const f2 dx = fma2(q[5], w, -x), dy = fma2(q[6], w, -y);
-      const f2 lhs = fma2(dx, dx, dy * dy);
-      const f2 w2 = w * w;
-      dR = fma2(nthr2f, w2, lhs);
-      sR = fma2(thr2f, w2, lhs);
-    }
-    const f2 eL = fma2(rel, sL, C), eR = fma2(rel, sR, C);
     const bool has1 = 2 * j + 1 < cnt;
-    // NaN or infinity on either side makes `sure` false: the fp64 path decides
-    const bool outL0 = dL.x > eL.x, outR0 = dR.x > eR.x, outL1 = dL.y > eL.y, outR1 = dR.y > eR.y;
-    bool in0 = dL.x < -eL.x && dR.x < -eR.x, in1 = dL.y < -eL.y && dR.y < -eR.y;
-    // decided: surely inside both cameras, or surely outside one of them
-    const bool ok0 = in0 || outL0 || outR0;
-    const bool ok1 = !has1 || in1 || outL1 || outR1;
+    ok1 = ok1 || !has1;
     if (!(ok0 && ok1)) {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -301,11 +322,14 @@ __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restr
         const double Xd = (double)f[0], Yd = (double)f[2], Zd = (double)f[4];
         bool in = inlier_one_camera(PL, Xd, Yd, Zd, (double)f[6], (double)f[8], thr, thr2);
         if (RECT) {
-          // the 3x3 part of P_right is that of P_left bit for bit: only its last column
-          // stays live through the loop
+          // P_right is P_left with another [3] (as numbers: [7] and [11] carry 0 * (t_x + tx)
+          // on top, which is not 0 only when t_x + tx is not finite; then P_right[3] is not
+          // finite either, the right x is infinite or NaN and the point is no inlier), so
+          // P_right[3] is all of it that stays live through the loop
           const double Pr[12] = {PL[0], PL[1], PL[2],  PR[3], PL[4], PL[5],
-                                 PL[6], PR[7], PL[8], PL[9], PL[10], PR[11]};
-          in = in && inlier_one_camera(Pr, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
+                                 PL[6], PL[7], PL[8], PL[9], PL[10], PL[11]};
+          in = in && fabs(PR[3]) <= 1.7976931348623157e308 &&
+               inlier_one_camera(Pr, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
         } else {
           in = in && inlier_one_camera(PR, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
         }

@@ -184,6 +184,7 @@ def test_packed_fp32_screening_never_changes_a_count(kind):
     n, H, thr = 3001, 6000, 2.0
     X = np.column_stack([rng.uniform(-40, 40, n), rng.uniform(-5, 5, n), rng.uniform(2, 400, n)])
     X[:40, 2] = rng.uniform(-5, 0.5, 40)            # behind / at the camera plane
+    X[40:44] *= 1e3                                 # farther than the screen accepts
     X = X.astype(np.float32)
     Rt = np.hstack([np.eye(3), np.array([[0.03], [-0.01], [-0.8]])])
     Rr = so.homogenous(cam.M_right) @ so.homogenous(Rt)
@@ -195,6 +196,9 @@ def test_packed_fp32_screening_never_changes_a_count(kind):
     mR = (pR + rng.normal(0, 0.3, (n, 2))).astype(np.float32)
     for k in range(0, 600, 3):                      # nudge some by single float32 ulps
         mL[k, 0] = np.nextafter(mL[k, 0], np.float32(np.inf if k % 2 else -np.inf))
+    mL[700, 0] = 3e5                                # a pixel coordinate beyond the screen's range
+    mR[900, 1] = np.nan
+    mL[1100, 1] = np.inf
     Rts, valid = perturbed_hypotheses(rng, Rt, H, good_fraction=0.5)
     Rts[0] = Rt
     Rts[1, 2, 3] = 0.0                              # t_z = 0: w ~ Z
@@ -212,6 +216,14 @@ def test_packed_fp32_screening_never_changes_a_count(kind):
         _lib.lib.slamhip_tune(2, 1)
     np.testing.assert_array_equal(got, ref)
     assert ref[0] > 0 and (ref[valid == 0] == -1).all() and ref[2] == 0
+    # a threshold nothing can meet: the reference's `error <= thr` is false everywhere
+    for bad_thr in (-1.0, float("nan")):
+        none = kernels.ransac_score(X, mL, mR, Rts[:64], valid[:64], cam.K, cam.M_right, bad_thr).cpu().numpy()
+        assert (none[valid[:64] == 1] == 0).all()
+        assert not kernels.ransac_mask(X, mL, mR, Rts[0], cam.K, cam.M_right, bad_thr).cpu().numpy().any()
+    # and one beyond the screen's range is still counted (in fp64)
+    wide = kernels.ransac_score(X, mL, mR, Rts[:64], valid[:64], cam.K, cam.M_right, 5e3).cpu().numpy()
+    assert wide[0] >= ref[0]
     # and against the reference arithmetic, outside the stated band
     eL, eR = so.hypothesis_errors(cam.K, cam.M_right, Rts[0], X, mL, mR)
     sure = (np.abs(eL - thr) > BAND) & (np.abs(eR - thr) > BAND)
