@@ -27,7 +27,8 @@ namespace {
 using namespace slamhip_dev;
 
 template <typename PT>
-__global__ __launch_bounds__(64) void p3p_kernel(const PT *__restrict__ pts,
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void p3p_kernel(const PT *__restrict__ pts,
                                                  const float *__restrict__ pix, int n_points,
                                                  const int32_t *__restrict__ idx4, int h, Kinv ki,
                                                  double *__restrict__ Rt_out,

@@ -41,7 +41,10 @@ __device__ bool triangle_frame(const double *p1, const double *p2, const double 
 // One minimal problem: X[4][3] world points, f[4][3] unit bearings, nrm[3] the
 // normalised image coordinates of the fourth point.  Returns false when no real
 // solution with positive depths exists; otherwise Rt[12] (row-major [R|t]).
-__device__ __noinline__ bool p3p_lane(const double (&X)[4][3], const double (&f)[4][3],
+#ifndef SLAMHIP_P3P_WAVES
+#define SLAMHIP_P3P_WAVES 3
+#endif
+__device__ __forceinline__ bool p3p_lane(const double (&X)[4][3], const double (&f)[4][3],
                                       const double (&nrm4)[2], double *bestRt) {
   double nrm[4][2];
   nrm[3][0] = nrm4[0];

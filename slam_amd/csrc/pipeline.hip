@@ -285,7 +285,8 @@ struct RansacParams {
 // hypotheses per pair: 1 in the round scheme; all of them (round 0 only, no replay
 // in between) when a call has so few pairs that launches, not arithmetic, bound it.
 // Pose table layout: rt[((pair * slots + slot) * 12 + element) * kHypPerRound + lane].
-__global__ __launch_bounds__(kBlock) void ransac_solve_kernel(
+__global__ __launch_bounds__(kBlock)
+__attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void ransac_solve_kernel(
     int round, int slots, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
