@@ -18,6 +18,8 @@
 // and any point whose two sides agree to 1e-10 relative is re-evaluated with the
 // reference's literal divide / sqrt / compare sequence, so the decision equals
 // the literal formula's decision on the same projection values.
+// For float32 points a packed-fp32 screen (ransac_device.h) decides most points two
+// at a time and leaves the rest to the fp64 test; the counts do not change.
 #include "common.h"
 
 #include <type_traits>
