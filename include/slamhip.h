@@ -54,8 +54,10 @@ const char *slamhip_strerror(int code);
  * the counts are identical either way), knob 3 = matcher block size (0 auto, 256 or
  * 128 queries per block), knob 4 = pair RANSAC launch scheme (0 auto: calls with at
  * most 64 pairs solve and count every hypothesis in one pass; 1 always rounds of 256
- * hypotheses; identical results; set it before sizing a workspace).  Process-global; not for use while other
- * threads are inside the library. */
+ * hypotheses; identical results; set it before sizing a workspace), knob 5 = sort
+ * algorithm (0 auto, 1 rank counting, 2 bitonic network where the segments fit it;
+ * same order).  Process-global; not for use while other threads are inside the
+ * library. */
 int slamhip_tune(int knob, int value);
 
 /* Diagnostics only: kernel-duration probe.  After begin(max_launches) the

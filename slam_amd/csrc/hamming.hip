@@ -433,6 +433,7 @@ ProfEvents g_prof;
 int g_force_variant = -1;  // diagnostics: -1 auto, bit0 = LDS, bits 1.. = Q
 int g_force_splits = 0;
 int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
+int g_force_sort = 0;      // 0 auto, 1 rank counting, 2 bitonic network (where it fits)
 
 MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                     int desc_bytes, long long n_out = -1, bool prepacked = false) {
@@ -587,7 +588,13 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 // chip, rank counting (many blocks per segment) otherwise.
 void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int32_t *d_off,
                  const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order, hipStream_t st) {
-  if (max_n <= kBitonicMax && n_segments >= 128) {
+  // One block per segment pays once there are segments enough to keep many CUs busy
+  // (measured: 500 segments of 1500 rows 30 us against 60; 64 segments the other way
+  // round); fewer segments sort faster by rank counting over many blocks.
+  bool bitonic = max_n <= kBitonicMax && n_segments >= 128;
+  if (g_force_sort == 1) bitonic = false;
+  if (g_force_sort == 2) bitonic = max_n <= kBitonicMax;
+  if (bitonic) {
     int N = 1;
     while (N < max_n) N <<= 1;
     hipLaunchKernelGGL(bitonic_sort_kernel, dim3(n_segments), dim3(256), (size_t)N * sizeof(uint32_t),
@@ -608,13 +615,15 @@ extern "C" {
 // knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
 // screening in the consensus counting kernels (1 on, 0 fp64 only; same counts),
 // knob 3 = matcher block size (0 auto, 256, 128), knob 4 = pair RANSAC launch scheme
-// (0 auto, 1 always rounds; set it before sizing the workspace).
+// (0 auto, 1 always rounds; set it before sizing the workspace), knob 5 = sort
+// (0 auto, 1 rank counting, 2 bitonic network where the segments fit it).
 int slamhip_tune(int knob, int value) {
   if (knob == 0) g_force_variant = value;
   else if (knob == 1) g_force_splits = value;
   else if (knob == 2) slamhip_internal::g_ransac_screen = value ? 1 : 0;
   else if (knob == 3) g_force_threads = value;
   else if (knob == 4) slamhip_internal::g_ransac_mode = value;
+  else if (knob == 5) g_force_sort = value;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
 }
