@@ -272,6 +272,12 @@ typedef struct slamhip_frontend_args {
   double pixel_thresh, disparity_min;    /* stereo filter (triangulation.py:104) */
   double ransac_thresh, p_success;       /* pnp.py:91, :104 */
   int32_t n_iter_max, refine_iters;
+  int32_t stereo_cross_check, temporal_cross_check; /* cv2.BFMatcher(crossCheck=True) for the
+                                            stereo / consecutive-frame matcher
+                                            (fill_database.py:69-70; both default to 0 as
+                                            run_slam.py:34-35): a query keeps, among the train
+                                            rows whose own best match it is, the closest one;
+                                            queries nobody chose have no match */
   uint64_t seed;                         /* device sampler seed */
   const int32_t *d_samples;  /* optional (F-1, n_iter_max, 4) sample indices into each pair's
                                 sorted temporal matches; NULL = device RNG */

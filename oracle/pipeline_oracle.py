@@ -15,10 +15,10 @@ import numpy as np
 from . import slam_oracle as so
 
 
-def _bf_match(q, t, knn2=None):
+def _bf_match(q, t, knn2=None, cross_check=False):
     """bf_match with an optional faster top-2 routine (the C oracle)."""
-    if knn2 is None:
-        return so.bf_match(q, t)
+    if knn2 is None or cross_check:
+        return so.bf_match(q, t, cross_check=cross_check)
     if len(q) == 0 or len(t) == 0:
         z = np.zeros(0, np.int32)
         return z, z, z
@@ -27,10 +27,11 @@ def _bf_match(q, t, knn2=None):
     return order.astype(np.int32), idx2[order, 0], dist2[order, 0]
 
 
-def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2, knn2=None):
-    """fill_database.py:155-169 for one frame."""
+def stereo_stage(cam, frame, pixel_thresh=4.0, disparity_min=1.2, knn2=None, cross_check=False):
+    """fill_database.py:155-169 for one frame (cross_check: the stereo matcher's
+    crossCheck, fill_database.py:69)."""
     kp_l, kp_r, des_l, des_r = frame
-    qi, ti, di = _bf_match(des_l, des_r, knn2)                              # :155
+    qi, ti, di = _bf_match(des_l, des_r, knn2, cross_check)                 # :155
     keep = so.stereo_filter(kp_l, kp_r, qi, ti, pixel_thresh, disparity_min)  # :158-160
     qi, ti, di = qi[keep], ti[keep], di[keep]
     X = so.triangulate_cv(cam.P_left, cam.P_right, kp_l[qi], kp_r[ti])      # :163
@@ -77,9 +78,10 @@ def ransac_loop(cam, X_corr, pix_L, pix_R, pixel_thresh, samples=None, solver=No
 
 
 def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
-                   p_success=0.99999, n_iter_max=2500, rng=None, knn2=None):
-    """fill_database.py:185-207 for one pair."""
-    qi, ti, di = _bf_match(prev["inlier_des_left"], curr["inlier_des_left"], knn2)  # :185
+                   p_success=0.99999, n_iter_max=2500, rng=None, knn2=None, cross_check=False):
+    """fill_database.py:185-207 for one pair (cross_check: the frame matcher's
+    crossCheck, fill_database.py:70)."""
+    qi, ti, di = _bf_match(prev["inlier_des_left"], curr["inlier_des_left"], knn2, cross_check)  # :185
     if len(curr["inlier_des_left"]) == 0:
         qi, ti, di = qi[:0], ti[:0], di[:0]
     X_corr = prev["xyz"][qi]                                                      # :189-190
@@ -91,8 +93,11 @@ def temporal_stage(cam, prev, curr, pixel_thresh=4.0, samples=None, solver=None,
     return out
 
 
-def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=True, **kw):
-    stereo = [stereo_stage(cam, f, pixel_thresh, disparity_min, knn2=kw.get("knn2")) for f in frames]
+def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=True,
+        stereo_cross_check=False, frame_cross_check=False, **kw):
+    stereo = [stereo_stage(cam, f, pixel_thresh, disparity_min, knn2=kw.get("knn2"),
+                           cross_check=stereo_cross_check) for f in frames]
+    kw = dict(kw, cross_check=frame_cross_check)
     pairs = []
     for p in range(len(frames) - 1):
         s = None if samples is None else samples[p]

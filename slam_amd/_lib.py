@@ -80,7 +80,9 @@ class FrontendArgs(C.Structure):
         ("K", C.c_double * 9), ("M_right", C.c_double * 12),
         ("P_left", C.c_double * 12), ("P_right", C.c_double * 12),
         ("pixel_thresh", _d), ("disparity_min", _d), ("ransac_thresh", _d), ("p_success", _d),
-        ("n_iter_max", _i32), ("refine_iters", _i32), ("seed", _u64), ("d_samples", _vp),
+        ("n_iter_max", _i32), ("refine_iters", _i32),
+        ("stereo_cross_check", _i32), ("temporal_cross_check", _i32),
+        ("seed", _u64), ("d_samples", _vp),
         ("d_st_count", _vp), ("d_st_left", _vp), ("d_st_right", _vp), ("d_st_dist", _vp),
         ("d_st_xyz", _vp), ("d_st_pix_left", _vp), ("d_st_pix_right", _vp), ("d_st_desc", _vp),
         ("d_tm_query", _vp), ("d_tm_train", _vp), ("d_tm_dist", _vp), ("d_tm_mask", _vp),

@@ -103,12 +103,16 @@ class FrontendResult:
 class TrackingFrontend:
     """Parameters follow the reference's defaults: disparity_min / pixel_thresh
     (run_slam.py:31-32; pixel_thresh is shared by the stereo filter and the PnP
-    inlier test, fill_database.py:81-82), p_success and n_iter_max (pnp.py:104-105)."""
+    inlier test, fill_database.py:81-82), p_success and n_iter_max (pnp.py:104-105),
+    no cross-check in either matcher (run_slam.py:34-35)."""
 
     def __init__(self, cam, disparity_min: float = 1.2, pixel_thresh: float = 4.0,
                  p_success: float = 0.99999, n_iter_max: int = 2500, refine_iters: int = 30,
-                 seed: int = 0):
+                 seed: int = 0, stereo_cross_check: bool = False, frame_cross_check: bool = False):
         self.cam = cam
+        # crossCheck of the stereo / consecutive-frame matcher (fill_database.py:69-70,
+        # run_slam.py:34-35)
+        self.stereo_cross_check, self.frame_cross_check = bool(stereo_cross_check), bool(frame_cross_check)
         self.disparity_min, self.pixel_thresh = float(disparity_min), float(pixel_thresh)
         self.p_success, self.n_iter_max = float(p_success), int(n_iter_max)
         self.refine_iters, self.seed = int(refine_iters), int(seed)
@@ -182,6 +186,7 @@ class TrackingFrontend:
         a.pixel_thresh, a.disparity_min = self.pixel_thresh, self.disparity_min
         a.ransac_thresh, a.p_success = self.pixel_thresh, self.p_success
         a.n_iter_max, a.refine_iters, a.seed = self.n_iter_max, self.refine_iters, self.seed
+        a.stereo_cross_check, a.temporal_cross_check = int(self.stereo_cross_check), int(self.frame_cross_check)
         d_samples = None
         if samples is not None:
             samples = np.ascontiguousarray(samples, dtype=np.int32)

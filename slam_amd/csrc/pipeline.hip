@@ -125,6 +125,48 @@ __global__ __launch_bounds__(kBlock) void stereo_points_kernel(
 }
 
 // --------------------------------------------------------------------------
+// crossCheck=True for many pairs at once.  The matcher runs with the roles
+// swapped (every train row finds its best query row, lowest query index on
+// ties); each train row then bids (distance, its own index) for that query row
+// with one atomic minimum on a key per query row, so a query keeps the closest
+// of the train rows that chose it, lowest train index on ties -- the fold of
+// cv2's batchDistance -- in O(rows) instead of a scan per query.
+// Pair p: train rows [tbase[p], +tcnt[p]) hold their choice in r_idx2 / r_dist2
+// (row-indexed like the rows themselves); query rows start at qbase[p].
+// --------------------------------------------------------------------------
+constexpr uint32_t kBidShift = 21, kBidIdxMask = (1u << kBidShift) - 1u, kNoBid = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(kBlock) void cross_bid_kernel(
+    const int32_t *__restrict__ tbase, const int32_t *__restrict__ tcnt_or_null,
+    const int32_t *__restrict__ qbase, const int32_t *__restrict__ r_idx2,
+    const int32_t *__restrict__ r_dist2, uint32_t *__restrict__ bid) {
+  const int p = blockIdx.y;
+  const int tb = tbase[p];
+  const int nt = tcnt_or_null ? tcnt_or_null[p] : tbase[p + 1] - tb;
+  const int t = blockIdx.x * kBlock + (int)threadIdx.x;
+  if (t >= nt) return;
+  const int who = r_idx2[2 * (size_t)(tb + t)];
+  if (who < 0) return;
+  const uint32_t d = (uint32_t)r_dist2[2 * (size_t)(tb + t)];
+  atomicMin(&bid[(size_t)qbase[p] + who], (d << kBidShift) | (uint32_t)t);
+}
+
+// bids -> the (index, distance) layout the forward matcher writes (second neighbour absent)
+__global__ __launch_bounds__(kBlock) void cross_decode_kernel(const uint32_t *__restrict__ bid, int n,
+                                                              int32_t *__restrict__ idx2,
+                                                              int32_t *__restrict__ dist2) {
+  const int i = blockIdx.x * kBlock + (int)threadIdx.x;
+  if (i >= n) return;
+  const uint32_t b = bid[i];
+  int2 oi, od;
+  oi.x = b == kNoBid ? -1 : (int32_t)(b & kBidIdxMask);
+  od.x = b == kNoBid ? -1 : (int32_t)(b >> kBidShift);
+  oi.y = od.y = -1;
+  reinterpret_cast<int2 *>(idx2)[i] = oi;
+  reinterpret_cast<int2 *>(dist2)[i] = od;
+}
+
+// --------------------------------------------------------------------------
 // Temporal stage: sorted matches -> 3D-2D correspondences of each pair.
 // --------------------------------------------------------------------------
 // Pair p matches the rows [qbase[p], +qcnt[p]) (query side: 3-D points) against
@@ -143,11 +185,19 @@ __global__ __launch_bounds__(kBlock) void temporal_gather_kernel(
   const int p = blockIdx.y;
   const int qb = qbase[p], tb = tbase[p], ob = obase[p];
   const int n = tcnt[p] > 0 ? qcnt[p] : 0;  // no train rows -> no matches
-  if (blockIdx.x == 0 && threadIdx.x == 0) tm_count[p] = n;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && n == 0) tm_count[p] = 0;
   const int r = blockIdx.x * kBlock + (int)threadIdx.x;
   if (r >= n) return;
   const int q = order2[ob + r];
   const int t = tidx2[2 * (size_t)(ob + q)];
+  // query rows without a match (cross-check) sort last: the matches are a prefix of
+  // the sorted rows, and the row that ends it writes the count
+  const bool next_matched = r + 1 < n && tidx2[2 * (size_t)(ob + order2[ob + r + 1])] >= 0;
+  if (t < 0) {
+    if (r == 0) tm_count[p] = 0;
+    return;
+  }
+  if (!next_matched) tm_count[p] = r + 1;
   const size_t o = (size_t)(ob + r);
   tm_query[o] = q;
   tm_train[o] = t;
@@ -597,6 +647,7 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
 struct Layout {
   int W;
   size_t idx2, dist2, order, packL, packR, knn, tidx2, tdist2, order2, cx, cpl, cpr, tcount, ransac, total;
+  size_t ridx2, rdist2, bid;   // cross-check only: the swapped matcher's result, the bids
   size_t knn_bytes;
 };
 
@@ -615,6 +666,14 @@ Layout make_layout(const slamhip_frontend_args *a) {
                                                            F > 1 ? F - 1 : 1, a->max_left, a->max_left,
                                                            a->desc_bytes);
   L.knn_bytes = k1 > k2 ? k1 : k2;
+  L.ridx2 = L.rdist2 = L.bid = 0;
+  if (a->stereo_cross_check || a->temporal_cross_check) {
+    const size_t k3 = slamhip_internal::knn2_workspace_bytes(a->n_right_total, a->n_left_total, F,
+                                                             a->max_right, a->max_left, a->desc_bytes);
+    if (k3 > L.knn_bytes) L.knn_bytes = k3;
+    const size_t rows = NL > NR ? NL : NR;
+    L.ridx2 = take(rows * 8); L.rdist2 = take(rows * 8); L.bid = take(NL * 4);
+  }
   L.knn = take(L.knn_bytes);
   L.tidx2 = take(NL * 8); L.tdist2 = take(NL * 8); L.order2 = take(NL * 4);
   L.cx = take(NL * 12); L.cpl = take(NL * 8); L.cpr = take(NL * 8);
@@ -692,11 +751,31 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   rc = slamhip_internal::pack_rows(a->d_des_left, a->n_left_total, packL, a->d_des_right,
                                    a->n_right_total, packR, a->desc_bytes, a->desc_stride, st);
   if (rc) return rc;
-  rc = slamhip_internal::knn2((const uint8_t *)packL, a->n_left_total, (const uint8_t *)packR,
-                              a->n_right_total, a->desc_bytes, W * 4, true, a->d_off_left, nullptr,
-                              a->d_off_right, nullptr, F, a->max_left, a->max_right, idx2, dist2,
-                              knn_ws, L.knn_bytes, st);
-  if (rc) return rc;
+  int32_t *ridx2 = (int32_t *)(base + L.ridx2), *rdist2 = (int32_t *)(base + L.rdist2);
+  uint32_t *bid = (uint32_t *)(base + L.bid);
+  if (!a->stereo_cross_check) {
+    rc = slamhip_internal::knn2((const uint8_t *)packL, a->n_left_total, (const uint8_t *)packR,
+                                a->n_right_total, a->desc_bytes, W * 4, true, a->d_off_left, nullptr,
+                                a->d_off_right, nullptr, F, a->max_left, a->max_right, idx2, dist2,
+                                knn_ws, L.knn_bytes, st);
+    if (rc) return rc;
+  } else {
+    if (hipMemsetAsync(bid, 0xFF, sizeof(uint32_t) * (size_t)a->n_left_total, st) != hipSuccess)
+      return SLAMHIP_ELAUNCH;
+    if (a->n_right_total > 0 && a->max_right > 0) {
+      rc = slamhip_internal::knn2((const uint8_t *)packR, a->n_right_total, (const uint8_t *)packL,
+                                  a->n_left_total, a->desc_bytes, W * 4, true, a->d_off_right, nullptr,
+                                  a->d_off_left, nullptr, F, a->max_right, a->max_left, ridx2, rdist2,
+                                  knn_ws, L.knn_bytes, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_right, kBlock), F), dim3(kBlock),
+                         0, st, a->d_off_right, (const int32_t *)nullptr, a->d_off_left, ridx2, rdist2,
+                         bid);
+    }
+    hipLaunchKernelGGL(cross_decode_kernel, dim3(slamhip_ceil_div(a->n_left_total, kBlock)),
+                       dim3(kBlock), 0, st, bid, a->n_left_total, idx2, dist2);
+    SLAMHIP_CHECK_LAUNCH();
+  }
   rc = slamhip_internal::sort_by_distance(dist2, 2, a->d_off_left, nullptr, F, a->max_left, order, st);
   if (rc) return rc;
   CamPair cam;
@@ -712,12 +791,29 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   if (F < 2) return SLAMHIP_OK;
 
   // ---- temporal stage: pair p = frames (p, p+1)
-  rc = slamhip_internal::knn2((const uint8_t *)a->d_st_desc, a->n_left_total,
-                              (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
-                              true, a->d_off_left, a->d_st_count, a->d_off_left + 1,
-                              a->d_st_count + 1, F - 1, a->max_left, a->max_left, tidx2, tdist2, knn_ws,
-                              L.knn_bytes, st);
-  if (rc) return rc;
+  if (!a->temporal_cross_check) {
+    rc = slamhip_internal::knn2((const uint8_t *)a->d_st_desc, a->n_left_total,
+                                (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
+                                true, a->d_off_left, a->d_st_count, a->d_off_left + 1,
+                                a->d_st_count + 1, F - 1, a->max_left, a->max_left, tidx2, tdist2, knn_ws,
+                                L.knn_bytes, st);
+    if (rc) return rc;
+  } else {
+    // the inliers of frame p+1 choose among those of frame p, then bid for them
+    if (hipMemsetAsync(bid, 0xFF, sizeof(uint32_t) * (size_t)a->n_left_total, st) != hipSuccess)
+      return SLAMHIP_ELAUNCH;
+    rc = slamhip_internal::knn2((const uint8_t *)a->d_st_desc, a->n_left_total,
+                                (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
+                                true, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left,
+                                a->d_st_count, F - 1, a->max_left, a->max_left, ridx2, rdist2, knn_ws,
+                                L.knn_bytes, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F - 1), dim3(kBlock),
+                       0, st, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left, ridx2, rdist2, bid);
+    hipLaunchKernelGGL(cross_decode_kernel, dim3(slamhip_ceil_div(a->n_left_total, kBlock)),
+                       dim3(kBlock), 0, st, bid, a->n_left_total, tidx2, tdist2);
+    SLAMHIP_CHECK_LAUNCH();
+  }
   rc = slamhip_internal::sort_by_distance(tdist2, 2, a->d_off_left, a->d_st_count, F - 1, a->max_left,
                                           order2, st);
   if (rc) return rc;

@@ -202,6 +202,61 @@ def test_run_sequence_tool_from_feature_cache(tmp_path):
         np.testing.assert_array_equal(back.pair(p)["mask"], res.pair(p)["mask"])
 
 
+@pytest.mark.parametrize("stereo_cc,frame_cc", [(True, False), (False, True), (True, True)])
+def test_batched_cross_check_equals_frame_at_a_time(stereo_cc, frame_cc):
+    """crossCheck in the stereo and / or the consecutive-frame matcher
+    (fill_database.py:69-70): match lists, their order, the inlier sets and
+    everything gathered from them equal the frame-at-a-time restatement, including a
+    frame with few features, one with an empty right image and duplicated rows that
+    force ties."""
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    n_iter = 256
+    cam, seq, frames = _sequence(6, 500, seed=23)
+    frames[2] = (frames[2][0][:200], frames[2][1][:320], frames[2][2][:200], frames[2][3][:320])
+    frames[4] = (frames[4][0], frames[4][1][:0], frames[4][2], frames[4][3][:0])
+    f1 = [a.copy() for a in frames[1]]
+    f1[2][10:20] = f1[2][30:40]          # equal left rows: several queries want the same train row
+    f1[3][50:55] = f1[3][60:65]          # equal right rows: ties between train rows
+    frames[1] = tuple(f1)
+    stereo_o = [po.stereo_stage(cam, f, cross_check=stereo_cc) for f in frames]
+    rng = np.random.default_rng(9)
+    samples = np.zeros((len(frames) - 1, n_iter, 4), np.int32)
+    pairs_n = []
+    for p in range(len(frames) - 1):
+        t = po.temporal_stage(cam, stereo_o[p], stereo_o[p + 1], n_iter_max=1, cross_check=frame_cc,
+                              samples=np.zeros((1, 4), np.int32) + np.arange(4))
+        pairs_n.append(t["n_matches"])
+        if t["n_matches"] >= 4:
+            samples[p] = np.stack([rng.choice(t["n_matches"], 4, replace=False) for _ in range(n_iter)])
+    fe = TrackingFrontend(cam, n_iter_max=n_iter, stereo_cross_check=stereo_cc, frame_cross_check=frame_cc)
+    res = fe.run(frames, samples=samples)
+    plain = TrackingFrontend(cam, n_iter_max=n_iter).run(frames, samples=samples)
+    fewer = 0
+    for f in range(len(frames)):
+        got, ref = res.frame(f), stereo_o[f]
+        for k in ("left_idx", "right_idx", "dist", "inlier_des_left", "pix_left", "pix_right"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"frame {f} {k}")
+        fewer += len(plain.frame(f)["left_idx"]) - len(got["left_idx"])
+    assert (fewer > 0) == stereo_cc            # the option really removes matches
+    assert len(res.frame(4)["left_idx"]) == 0
+    for p in range(len(frames) - 1):
+        got = res.pair(p)
+        ref = po.temporal_stage(cam, stereo_o[p], stereo_o[p + 1], n_iter_max=1, cross_check=frame_cc,
+                                samples=np.zeros((1, 4), np.int32) + np.arange(4))
+        assert got["n_matches"] == ref["n_matches"] == pairs_n[p], p
+        for k in ("query_idx", "train_idx", "dist"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"pair {p} {k}")
+        if frame_cc:
+            assert len(set(got["train_idx"].tolist())) == len(got["train_idx"])   # one-to-one
+        if got["n_matches"] >= 4 and got["best_index"] >= 0:
+            X = stereo_o[p]["xyz"][ref["query_idx"]]
+            eL, eR = so.hypothesis_errors(cam.K, cam.M_right, got["Rt_ransac"], X, ref["pix_L"], ref["pix_R"])
+            refmask = (eL <= 4.0) & (eR <= 4.0)
+            bad = np.flatnonzero(refmask != got["mask"])
+            assert all(min(abs(eL[i] - 4.0), abs(eR[i] - 4.0)) < 1e-6 for i in bad)
+    assert np.abs(res.pair(0)["Rt"][:, 3] - seq.relative_pose(1)[:, 3]).max() < 0.1
+
+
 @pytest.mark.parametrize("scheme", [1, 0])       # tune knob 4: 1 = rounds, 0 = auto (single pass here)
 @pytest.mark.parametrize("seed,n_iter,clutter,thresh", [(31, 1100, 0.72, 4.0), (5, 257, 0.5, 2.0),
                                                         (77, 2500, 0.8, 1.5)])

@@ -33,6 +33,8 @@ def main(argv=None):
     ap.add_argument("--synthesize", type=int, default=0)
     ap.add_argument("--disp-min", type=float, default=1.2)
     ap.add_argument("--pix-thresh", type=float, default=4.0)
+    ap.add_argument("--stereo-cross-check", action="store_true")   # as run_slam.py:34-35
+    ap.add_argument("--frame-cross-check", action="store_true")
     args = ap.parse_args(argv)
 
     import torch
@@ -62,7 +64,9 @@ def main(argv=None):
         dist.barrier()          # the synthesised cache is complete before anyone lists it
 
     frames = feature_cache.FeatureCache(args.features, args.max_frames)
-    fe = TrackingFrontend(cam, disparity_min=args.disp_min, pixel_thresh=args.pix_thresh, seed=0)
+    fe = TrackingFrontend(cam, disparity_min=args.disp_min, pixel_thresh=args.pix_thresh, seed=0,
+                          stereo_cross_check=args.stereo_cross_check,
+                          frame_cross_check=args.frame_cross_check)
     t0 = time.perf_counter()
     res = sharding.run_sharded(fe, frames, rank, world, group)
     torch.cuda.synchronize()
