@@ -44,6 +44,95 @@ __device__ __forceinline__ void top2_push(uint32_t &b1, uint32_t &b2, uint32_t k
 }
 
 // ---------------------------------------------------------------------------
+// Scan of one LDS tile of 16-word train rows by a wave whose lanes each hold one
+// query, written out instruction by instruction.
+//
+// Why: measured on gfx950 (tools/issue_probe2), v_xor_b32 with two VGPR sources
+// issues every ~2.2 cycles per wave, v_bcnt_u32_b32 (like the shifts, min/max/
+// med3 and every other VOP3 integer operation tried) every ~4, and a stream that
+// alternates the two kinds pays for every switch: 16 xors in a row followed by
+// the 16 dependent popcount-accumulates, with the next row's LDS reads already
+// in flight, reaches 1.27e12 row compares/s chip-wide against 1.07e12 for
+// xor/bcnt/xor/bcnt, which is what the compiler schedules.  Tying compiler-
+// allocated scalars to the 4-register tuples of ds_read_b128 costs copies and
+// early waits, so the row buffers are fixed registers: A = v[30:45],
+// B = v[46:61], v62 = distance, v63 = LDS address.
+//
+// Row r of the tile has key index key0 + r; the running top-2 keys are updated
+// in train-index order.  The read of "row + 2" at the end of the tile may touch
+// up to two rows past `rows`: the tile is allocated two rows longer for that.
+// ---------------------------------------------------------------------------
+#define SLAMHIP_LD_ROW(v0, v1, v2, v3, o0, o1, o2, o3)                                          \
+  "ds_read_b128 v[" #v0 ":" #v0 "+3], v63 offset:" #o0 "\n"                                     \
+  "ds_read_b128 v[" #v1 ":" #v1 "+3], v63 offset:" #o1 "\n"                                     \
+  "ds_read_b128 v[" #v2 ":" #v2 "+3], v63 offset:" #o2 "\n"                                     \
+  "ds_read_b128 v[" #v3 ":" #v3 "+3], v63 offset:" #o3 "\n"
+#define SLAMHIP_LD_A(off0, off1, off2, off3) SLAMHIP_LD_ROW(30, 34, 38, 42, off0, off1, off2, off3)
+#define SLAMHIP_LD_B(off0, off1, off2, off3) SLAMHIP_LD_ROW(46, 50, 54, 58, off0, off1, off2, off3)
+#define SLAMHIP_XR(r, qi) "v_xor_b32 v" #r ", %" #qi ", v" #r "\n"
+#define SLAMHIP_BR(r) "v_bcnt_u32_b32 v62, v" #r ", v62\n"
+// operands %5..%20 are the query words
+#define SLAMHIP_DIST_A                                                                          \
+  SLAMHIP_XR(30, 5) SLAMHIP_XR(31, 6) SLAMHIP_XR(32, 7) SLAMHIP_XR(33, 8) SLAMHIP_XR(34, 9)      \
+  SLAMHIP_XR(35, 10) SLAMHIP_XR(36, 11) SLAMHIP_XR(37, 12) SLAMHIP_XR(38, 13) SLAMHIP_XR(39, 14) \
+  SLAMHIP_XR(40, 15) SLAMHIP_XR(41, 16) SLAMHIP_XR(42, 17) SLAMHIP_XR(43, 18) SLAMHIP_XR(44, 19) \
+  SLAMHIP_XR(45, 20)                                                                            \
+  "v_bcnt_u32_b32 v62, v30, 0\n"                                                                \
+  SLAMHIP_BR(31) SLAMHIP_BR(32) SLAMHIP_BR(33) SLAMHIP_BR(34) SLAMHIP_BR(35) SLAMHIP_BR(36)     \
+  SLAMHIP_BR(37) SLAMHIP_BR(38) SLAMHIP_BR(39) SLAMHIP_BR(40) SLAMHIP_BR(41) SLAMHIP_BR(42)     \
+  SLAMHIP_BR(43) SLAMHIP_BR(44) SLAMHIP_BR(45)
+#define SLAMHIP_DIST_B                                                                          \
+  SLAMHIP_XR(46, 5) SLAMHIP_XR(47, 6) SLAMHIP_XR(48, 7) SLAMHIP_XR(49, 8) SLAMHIP_XR(50, 9)      \
+  SLAMHIP_XR(51, 10) SLAMHIP_XR(52, 11) SLAMHIP_XR(53, 12) SLAMHIP_XR(54, 13) SLAMHIP_XR(55, 14) \
+  SLAMHIP_XR(56, 15) SLAMHIP_XR(57, 16) SLAMHIP_XR(58, 17) SLAMHIP_XR(59, 18) SLAMHIP_XR(60, 19) \
+  SLAMHIP_XR(61, 20)                                                                            \
+  "v_bcnt_u32_b32 v62, v46, 0\n"                                                                \
+  SLAMHIP_BR(47) SLAMHIP_BR(48) SLAMHIP_BR(49) SLAMHIP_BR(50) SLAMHIP_BR(51) SLAMHIP_BR(52)     \
+  SLAMHIP_BR(53) SLAMHIP_BR(54) SLAMHIP_BR(55) SLAMHIP_BR(56) SLAMHIP_BR(57) SLAMHIP_BR(58)     \
+  SLAMHIP_BR(59) SLAMHIP_BR(60) SLAMHIP_BR(61)
+// key = dist << 21 | index; b2 = med3(b1, b2, key); b1 = min(b1, key)   (%0 = b1, %1 = b2, %3 = index)
+#define SLAMHIP_PUSH                                                                            \
+  "v_lshl_or_b32 v62, v62, 21, %3\n"                                                            \
+  "v_med3_u32 %1, %0, %1, v62\n"                                                                \
+  "v_min_u32 %0, %0, v62\n"
+
+__device__ __forceinline__ void scan_tile16(uint32_t lds_addr, int rows, uint32_t key0,
+                                            const uint32_t (&q)[16], uint32_t &b1, uint32_t &b2) {
+  asm volatile(
+      "v_mov_b32 v63, %4\n"
+      SLAMHIP_LD_A(0, 16, 32, 48)
+      "s_cmp_lt_u32 %2, 2\n"
+      "s_cbranch_scc1 SCAN_TAIL_%=\n"
+      "SCAN_LOOP_%=:\n"
+      SLAMHIP_LD_B(64, 80, 96, 112)
+      "s_waitcnt lgkmcnt(4)\n"
+      SLAMHIP_DIST_A
+      SLAMHIP_PUSH
+      "v_add_u32 v63, 0x80, v63\n"
+      SLAMHIP_LD_A(0, 16, 32, 48)
+      "s_add_u32 %3, %3, 1\n"
+      "s_waitcnt lgkmcnt(4)\n"
+      SLAMHIP_DIST_B
+      SLAMHIP_PUSH
+      "s_add_u32 %3, %3, 1\n"
+      "s_sub_u32 %2, %2, 2\n"
+      "s_cmp_lt_u32 %2, 2\n"
+      "s_cbranch_scc0 SCAN_LOOP_%=\n"
+      "SCAN_TAIL_%=:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_cmp_eq_u32 %2, 0\n"
+      "s_cbranch_scc1 SCAN_DONE_%=\n"
+      SLAMHIP_DIST_A
+      SLAMHIP_PUSH
+      "SCAN_DONE_%=:\n"
+      : "+v"(b1), "+v"(b2), "+s"(rows), "+s"(key0)
+      : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]),
+        "v"(q[7]), "v"(q[8]), "v"(q[9]), "v"(q[10]), "v"(q[11]), "v"(q[12]), "v"(q[13]), "v"(q[14]),
+        "v"(q[15])
+      : "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory");
+}
+
+// ---------------------------------------------------------------------------
 // Row packing: (n, desc_bytes) rows `stride` bytes apart -> (n, W) dwords,
 // zero padded.  Handles both descriptor sets of a call in one launch.
 // ---------------------------------------------------------------------------
@@ -138,7 +227,7 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
   for (int q = 0; q < Q; ++q) b1[q] = b2[q] = kNoKey;
 
   if constexpr (USE_LDS) {
-    __shared__ uint4 tile[kTileRows * W / 4];
+    __shared__ uint4 tile[(kTileRows + 2) * W / 4];   // + 2: see scan_tile16
     for (int tile_begin = r_begin; tile_begin < r_end; tile_begin += kTileRows) {
       const int rows = min(kTileRows, r_end - tile_begin);
       __syncthreads();
@@ -147,6 +236,12 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
       __syncthreads();
       // wave-uniform trip count kept in an SGPR so the loop control stays off the VALU
       const int rows_u = __builtin_amdgcn_readfirstlane(rows);
+      if constexpr (Q == 1 && W == 16) {
+        const uint32_t lds_addr =
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tile;
+        scan_tile16(lds_addr, rows_u, (uint32_t)__builtin_amdgcn_readfirstlane(tile_begin), qv[0],
+                    b1[0], b2[0]);
+      } else {
       int jj = 0;
       for (; jj + 2 <= rows_u; jj += 2) {
         uint32_t ta[W], tb[W];
@@ -188,6 +283,7 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
           for (int w = 0; w < W; ++w) acc += __builtin_popcount(tw[w] ^ qv[q][w]);
           top2_push(b1[q], b2[q], (acc << kKeyShift) | jidx);
         }
+      }
       }
     }
   } else {
