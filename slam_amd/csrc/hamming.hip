@@ -91,10 +91,15 @@ __device__ __forceinline__ void top2_push(uint32_t &b1, uint32_t &b2, uint32_t k
   SLAMHIP_BR(53) SLAMHIP_BR(54) SLAMHIP_BR(55) SLAMHIP_BR(56) SLAMHIP_BR(57) SLAMHIP_BR(58)     \
   SLAMHIP_BR(59) SLAMHIP_BR(60) SLAMHIP_BR(61)
 // key = dist << 21 | index; b2 = med3(b1, b2, key); b1 = min(b1, key)   (%0 = b1, %1 = b2, %3 = index)
-#define SLAMHIP_PUSH                                                                            \
-  "v_lshl_or_b32 v62, v62, 21, %3\n"                                                            \
-  "v_med3_u32 %1, %0, %1, v62\n"                                                                \
-  "v_min_u32 %0, %0, v62\n"
+#define SLAMHIP_PUSH_R(r)                                                                       \
+  "v_lshl_or_b32 v" #r ", v" #r ", 21, %3\n"                                                    \
+  "v_med3_u32 %1, %0, %1, v" #r "\n"                                                            \
+  "v_min_u32 %0, %0, v" #r "\n"
+#define SLAMHIP_PUSH SLAMHIP_PUSH_R(62)
+#define SLAMHIP_SCAN_CLOBBERS                                                                   \
+  "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",     \
+  "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",     \
+  "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory"
 
 __device__ __forceinline__ void scan_tile16(uint32_t lds_addr, int rows, uint32_t key0,
                                             const uint32_t (&q)[16], uint32_t &b1, uint32_t &b2) {
@@ -129,7 +134,66 @@ __device__ __forceinline__ void scan_tile16(uint32_t lds_addr, int rows, uint32_
       : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]),
         "v"(q[7]), "v"(q[8]), "v"(q[9]), "v"(q[10]), "v"(q[11]), "v"(q[12]), "v"(q[13]), "v"(q[14]),
         "v"(q[15])
-      : "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory");
+      : SLAMHIP_SCAN_CLOBBERS);
+}
+
+// The same for 8-word rows (descriptors of at most 32 bytes): a buffer holds two
+// consecutive rows, compared as 16 xors and two popcount chains (the second one
+// accumulates in its own first word), four rows per loop trip.  Operands %5..%12 are
+// the query words.  The reads past the last row stay within two rows.
+#define SLAMHIP_XR8(base)                                                                       \
+  SLAMHIP_XR_(base, 0, 5) SLAMHIP_XR_(base, 1, 6) SLAMHIP_XR_(base, 2, 7) SLAMHIP_XR_(base, 3, 8) \
+  SLAMHIP_XR_(base, 4, 9) SLAMHIP_XR_(base, 5, 10) SLAMHIP_XR_(base, 6, 11) SLAMHIP_XR_(base, 7, 12)
+#define SLAMHIP_XR_(base, i, qi) "v_xor_b32 v[" #base "+" #i "], %" #qi ", v[" #base "+" #i "]\n"
+#define SLAMHIP_BC_(acc, base, i) "v_bcnt_u32_b32 v" #acc ", v[" #base "+" #i "], v" #acc "\n"
+#define SLAMHIP_CHAIN8(acc, base)                                                               \
+  "v_bcnt_u32_b32 v" #acc ", v[" #base "+0], 0\n"                                               \
+  SLAMHIP_BC_(acc, base, 1) SLAMHIP_BC_(acc, base, 2) SLAMHIP_BC_(acc, base, 3)                 \
+  SLAMHIP_BC_(acc, base, 4) SLAMHIP_BC_(acc, base, 5) SLAMHIP_BC_(acc, base, 6) SLAMHIP_BC_(acc, base, 7)
+// two rows of a buffer starting at register `lo` (second row at `hi` = lo + 8)
+#define SLAMHIP_DIST8X2(lo, hi)                                                                 \
+  SLAMHIP_XR8(lo) SLAMHIP_XR8(hi) SLAMHIP_CHAIN8(62, lo) SLAMHIP_CHAIN8(hi, hi)                 \
+  SLAMHIP_PUSH_R(62) "s_add_u32 %3, %3, 1\n" SLAMHIP_PUSH_R(hi) "s_add_u32 %3, %3, 1\n"
+#define SLAMHIP_DIST8X1(lo)                                                                     \
+  SLAMHIP_XR8(lo) SLAMHIP_CHAIN8(62, lo) SLAMHIP_PUSH_R(62) "s_add_u32 %3, %3, 1\n"
+
+__device__ __forceinline__ void scan_tile8(uint32_t lds_addr, int rows, uint32_t key0,
+                                           const uint32_t (&q)[8], uint32_t &b1, uint32_t &b2) {
+  asm volatile(
+      "v_mov_b32 v63, %4\n"
+      SLAMHIP_LD_A(0, 16, 32, 48)
+      "s_cmp_lt_u32 %2, 4\n"
+      "s_cbranch_scc1 SCAN_TAIL_%=\n"
+      "SCAN_LOOP_%=:\n"
+      SLAMHIP_LD_B(64, 80, 96, 112)
+      "s_waitcnt lgkmcnt(4)\n"
+      SLAMHIP_DIST8X2(30, 38)
+      "v_add_u32 v63, 0x80, v63\n"
+      SLAMHIP_LD_A(0, 16, 32, 48)
+      "s_waitcnt lgkmcnt(4)\n"
+      SLAMHIP_DIST8X2(46, 54)
+      "s_sub_u32 %2, %2, 4\n"
+      "s_cmp_lt_u32 %2, 4\n"
+      "s_cbranch_scc0 SCAN_LOOP_%=\n"
+      "SCAN_TAIL_%=:\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      "s_cmp_eq_u32 %2, 0\n"
+      "s_cbranch_scc1 SCAN_DONE_%=\n"
+      SLAMHIP_DIST8X1(30)
+      "s_cmp_eq_u32 %2, 1\n"
+      "s_cbranch_scc1 SCAN_DONE_%=\n"
+      SLAMHIP_DIST8X1(38)
+      "s_cmp_eq_u32 %2, 2\n"
+      "s_cbranch_scc1 SCAN_DONE_%=\n"
+      "ds_read_b128 v[46:49], v63 offset:64\n"
+      "ds_read_b128 v[50:53], v63 offset:80\n"
+      "s_waitcnt lgkmcnt(0)\n"
+      SLAMHIP_DIST8X1(46)
+      "SCAN_DONE_%=:\n"
+      : "+v"(b1), "+v"(b2), "+s"(rows), "+s"(key0)
+      : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]),
+        "v"(q[7])
+      : SLAMHIP_SCAN_CLOBBERS);
 }
 
 // ---------------------------------------------------------------------------
@@ -236,11 +300,12 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
       __syncthreads();
       // wave-uniform trip count kept in an SGPR so the loop control stays off the VALU
       const int rows_u = __builtin_amdgcn_readfirstlane(rows);
-      if constexpr (Q == 1 && W == 16) {
+      if constexpr (Q == 1 && W <= 16) {
         const uint32_t lds_addr =
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tile;
-        scan_tile16(lds_addr, rows_u, (uint32_t)__builtin_amdgcn_readfirstlane(tile_begin), qv[0],
-                    b1[0], b2[0]);
+        const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane(tile_begin);
+        if constexpr (W == 16) scan_tile16(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
+        else scan_tile8(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
       } else {
       int jj = 0;
       for (; jj + 2 <= rows_u; jj += 2) {

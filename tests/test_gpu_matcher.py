@@ -91,6 +91,28 @@ def test_both_block_sizes_with_ties_and_ragged_batches(threads, splits):
         _lib.lib.slamhip_tune(1, 0)
 
 
+@pytest.mark.parametrize("desc_bytes", [61, 32, 17])
+def test_every_train_row_count_through_the_tile_scan(desc_bytes):
+    """The tile scan is unrolled by two (16-word rows) or four (8-word rows) train rows
+    with a tail, over LDS tiles of 128 rows: every row count from 1 to 140 and a few
+    around further tile boundaries, one block scanning all of them (splits = 1), with
+    many equal distances, in one ragged batched call."""
+    from slam_amd import _lib, kernels
+    _lib.lib.slamhip_tune(1, 1)
+    rng = np.random.default_rng(desc_bytes)
+    nts = list(range(1, 141)) + [255, 256, 257, 258, 259, 383, 384, 385, 386, 387]
+    qs = [rng.integers(0, 3, (70, desc_bytes), dtype=np.uint8) for _ in nts]
+    ts = [rng.integers(0, 3, (n, desc_bytes), dtype=np.uint8) for n in nts]
+    q_off = (np.arange(len(nts) + 1) * 70).astype(np.int32)
+    t_off = np.concatenate([[0], np.cumsum(nts)]).astype(np.int32)
+    i, d = kernels.hamming_knn2_batched(np.vstack(qs), np.vstack(ts), q_off, t_off)
+    i, d = i.cpu().numpy(), d.cpu().numpy()
+    for p, n in enumerate(nts):
+        ei, ed = so.hamming_knn2(qs[p], ts[p])
+        np.testing.assert_array_equal(i[q_off[p]:q_off[p + 1]], ei, err_msg=f"{n} train rows")
+        np.testing.assert_array_equal(d[q_off[p]:q_off[p + 1]], ed, err_msg=f"{n} train rows")
+
+
 def test_empty_inputs():
     q = np.zeros((5, 61), np.uint8)
     i, d = _run(q, np.zeros((0, 61), np.uint8))
