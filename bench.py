@@ -13,7 +13,10 @@ pair: pairs shard with no data-path collective, so scaling is weak.
 Prints ONE JSON line on rank 0.  `value` = Hamming compares per second over all
 ranks.  `roofline` prices the dominant kernel (hamming_top2_kernel) in int32
 VALU lane-operations: 2*ceil(D/4) = 32 per compare (16 v_xor_b32 + 16
-v_bcnt_u32_b32), against 4 SIMD x 32 lanes x 256 CU x 2.4 GHz = 78.6 Tlane-op/s.
+v_bcnt_u32_b32).  On gfx950 a SIMD issues v_xor_b32 at 32 lanes per clock and
+v_bcnt_u32_b32 at 16 (tools/issue_probe2.hip, profiles/r1/issue_probe2.log), so
+a wave needs 16 x 2 + 16 x 4 = 96 cycles per train row: peak = 1024 SIMDs x 64
+compares / 96 cycles x 2.4 GHz = 1.64e12 compares/s = 52.4 Tlane-op/s.
 `cpu_baseline` times the C/OpenMP restatement (oracle/hamming_oracle.c) of the
 same workload on the host cores of this machine.
 """
@@ -36,10 +39,20 @@ if ROOT not in sys.path:
 NQ = NT = 8192
 DESC_BYTES = 61
 RATIO = 0.8
-PEAK_LANE_OPS = 4 * 32 * 256 * 2.4e9      # int32 VALU lane-ops/s (MI355X, 2-cycle wave64 issue)
-# What the PMC counters show this chip doing for v_xor/v_bcnt: one wave64 VALU
-# instruction per 4 cycles per SIMD (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU = 1 quad-cycle).
-MEASURED_ISSUE_LANE_OPS = 4 * 16 * 256 * 2.4e9
+CLOCK_HZ = 2.4e9
+N_SIMD = 256 * 4
+UNIFORM_PEAK_LANE_OPS = N_SIMD * 32 * CLOCK_HZ      # every VALU op at the 2-cycle wave64 rate: 78.6 T
+# Issue cost per wave64 instruction measured with tools/issue_probe2.hip: v_xor_b32 (VGPR
+# sources) 2 cycles like v_add/v_fma, v_bcnt_u32_b32 4 cycles like shifts, min/max, med3.
+CYCLES_XOR, CYCLES_BCNT = 2, 4
+
+
+def peak_compares_per_sec(desc_bytes):
+    words = (desc_bytes + 3) // 4
+    return N_SIMD * 64 * CLOCK_HZ / (words * (CYCLES_XOR + CYCLES_BCNT))
+
+
+PEAK_LANE_OPS = peak_compares_per_sec(DESC_BYTES) * 2 * ((DESC_BYTES + 3) // 4)   # 52.4 T for 61 B
 # HBM-side bytes per top-2 launch from the committed PMC passes (profiles/r1/pmc_matcher8k.txt):
 # FETCH_SIZE 2327 KB x2 (gfx950 wide-read correction) + WRITE_SIZE 4096 KB.
 PMC_TRAFFIC_BYTES = (2327 * 2 + 4096) * 1024
@@ -216,7 +229,7 @@ def bench_sweep(kernels):
             ops = 2 * ((nbytes + 3) // 4)
             rows.append({"n": n, "desc_bytes": nbytes, "us_per_call": dt * 1e6,
                          "compares_per_sec": n * n / dt,
-                         "frac_of_measured_issue_rate": n * n * ops / dt / MEASURED_ISSUE_LANE_OPS})
+                         "frac_of_peak": n * n / dt / peak_compares_per_sec(nbytes)})
     return rows
 
 
@@ -420,8 +433,11 @@ def main():
                          "achieved": achieved / 1e12, "peak": PEAK_LANE_OPS / 1e12,
                          "unit": "Tlane-op/s", "frac": achieved / PEAK_LANE_OPS,
                          "ops_per_compare": OPS_PER_COMPARE,
+                         "peak_model": "16 v_xor_b32 at 2 cycles + 16 v_bcnt_u32_b32 at 4 cycles per wave64 "
+                                       "and train row (issue rates measured with tools/issue_probe2.hip) "
+                                       "on 1024 SIMDs at 2.4 GHz = 1.64e12 compares/s",
                          "kernel_us": kernel_s * 1e6, "launches_timed": n_launch,
-                         "frac_of_measured_issue_rate": achieved / MEASURED_ISSUE_LANE_OPS,
+                         "frac_if_every_op_issued_in_2_cycles": achieved / UNIFORM_PEAK_LANE_OPS,
                          "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
                          "traffic": PMC_TRAFFIC_BYTES,
                          "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes "

@@ -395,21 +395,26 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
   }
 }
 
-// Folds the per-split key pairs.  Block = 64 query rows x 4 split groups: lane
-// (row, g) folds splits g, g+4, ... (coalesced over rows), the four groups meet
-// in LDS.  Optionally applies the ratio test to the final pair.
+// Folds the per-split key pairs.  Block = 16 query rows x 16 split groups: lane
+// (row, g) folds splits g, g+16, ... (16 rows x 8 bytes = one 128-byte line per
+// split), the sixteen groups meet in LDS and lane (row, 0) folds them in split order
+// of the groups.  Many small blocks: the fold is latency-bound, and 64-row blocks
+// left half of the CUs without work for 8192 rows.  Optionally applies the ratio
+// test to the final pair.
+constexpr int kMergeRows = 16, kMergeGroups = 16;
+
 __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restrict__ partial,
                                                             int nq_total, int n_splits,
                                                             int32_t *__restrict__ idx2,
                                                             int32_t *__restrict__ dist2,
                                                             double ratio,
                                                             uint8_t *__restrict__ keep) {
-  __shared__ uint2 part[4][64];
-  const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int row = blockIdx.x * 64 + lane;
+  __shared__ uint2 part[kMergeGroups][kMergeRows];
+  const int lane = threadIdx.x % kMergeRows, g = threadIdx.x / kMergeRows;
+  const int row = blockIdx.x * kMergeRows + lane;
   uint32_t b1 = kNoKey, b2 = kNoKey;
   if (row < nq_total) {
-    for (int s = g; s < n_splits; s += 4) {
+    for (int s = g; s < n_splits; s += kMergeGroups) {
       const uint2 p = partial[(size_t)s * nq_total + row];
       top2_push(b1, b2, p.x);
       top2_push(b1, b2, p.y);
@@ -419,7 +424,7 @@ __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restr
   __syncthreads();
   if (g != 0 || row >= nq_total) return;
 #pragma unroll
-  for (int k = 1; k < 4; ++k) {
+  for (int k = 1; k < kMergeGroups; ++k) {
     const uint2 p = part[k][lane];
     top2_push(b1, b2, p.x);
     top2_push(b1, b2, p.y);
@@ -733,7 +738,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.splits > 1) {
-    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(n_out_total, 64)), dim3(256), 0,
+    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(n_out_total, kMergeRows)), dim3(256), 0,
                        st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
     SLAMHIP_CHECK_LAUNCH();
   } else if (d_keep != nullptr) {
