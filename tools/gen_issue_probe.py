@@ -51,16 +51,44 @@ OPS = {
     "v_ffbh_u32":       "v_ffbh_u32 {d}, {a}",
     "v_bfrev_b32":      "v_bfrev_b32 {d}, {a}",
     "v_cvt_f32_ubyte0": "v_cvt_f32_ubyte0 {d}, {a}",
+    # lane-mask consumers and producers (the consensus-counting loop)
+    "v_cndmask_sgpr":   "v_cndmask_b32_e64 {d}, {a}, {d}, s[22:23]",
+    "v_cndmask_imm":    "v_cndmask_b32_e64 {d}, 0, 1, s[22:23]",
+    "v_addc_vcc":       "v_addc_co_u32 {d}, vcc, 0, {d}, vcc",
+    "v_addc_sgpr":      "v_addc_co_u32_e64 {d}, s[24:25], 0, {d}, s[22:23]",
+    "v_cmp_lt_f32_vcc": "v_cmp_lt_f32 vcc, {a}, {d}",
+    "v_cmp_lt_f32_sgpr": "v_cmp_lt_f32_e64 s[24:25], {a}, {d}",
+    "v_cmp_abs_f32":    "v_cmp_lt_f32_e64 s[24:25], |{a}|, {d}",
+    "v_max_f32":        "v_max_f32 {d}, {a}, {d}",
+    "v_min_f32":        "v_min_f32 {d}, {a}, {d}",
+    "v_med3_f32":       "v_med3_f32 {d}, {d}, {a}, {b}",
+    "v_mul_f32":        "v_mul_f32 {d}, {a}, {d}",
+    "v_pk_mul_f32":     None,
+    "v_pk_add_f32":     None,
+    "v_fma_f64":        None,
+    "v_or_b32":         "v_or_b32 {d}, {a}, {d}",
+    "v_xor_neg":        "v_fma_f32 {d}, {a}, {b}, -{d}",
+    "v_subrev_u32":     "v_subrev_u32 {d}, {a}, {d}",
+    "v_ashrrev_i32":    "v_ashrrev_i32 {d}, 31, {d}",
+    "v_and_sgpr":       "v_and_b32 {d}, s22, {d}",
+    "v_xor_lit":        "v_xor_b32 {d}, 0x80000000, {d}",
 }
 
 
 def single(op):
     t = OPS[op]
     lines = []
-    if t is None:   # v_pk_fma_f32 on pairs
+    if t is None:   # packed / 64-bit operations on register pairs
         for i in range(0, 32, 2):
             d = f"v[{i % 16 // 2 * 2}:{i % 16 // 2 * 2 + 1}]"
-            lines.append(f"v_pk_fma_f32 {d}, v[16:17], v[32:33], {d}")
+            if op == "v_pk_fma_f32":
+                lines.append(f"v_pk_fma_f32 {d}, v[16:17], v[32:33], {d}")
+            elif op == "v_pk_mul_f32":
+                lines.append(f"v_pk_mul_f32 {d}, v[16:17], {d}")
+            elif op == "v_pk_add_f32":
+                lines.append(f"v_pk_add_f32 {d}, v[16:17], {d}")
+            else:
+                lines.append(f"v_fma_f64 {d}, v[16:17], v[32:33], {d}")
         return lines
     for i in range(32):
         lines.append(t.format(d=f"v{i % 16}", a=f"v{16 + i % 16}", b=f"v{32 + i % 16}"))
@@ -167,13 +195,15 @@ __global__ __launch_bounds__(256) void {name}(uint32_t *out, unsigned long long 
   asm volatile(
       "v_mov_b32 {addr}, 0\\n"
       "s_mov_b32 s20, %1\\n"
+      "s_mov_b32 s22, 0x55555555\\n"
+      "s_mov_b32 s23, 0x33333333\\n"
       "PROBE_LOOP_%=:\\n"
       "{asm}\\n"
       "s_sub_u32 s20, s20, 1\\n"
       "s_cmp_lg_u32 s20, 0\\n"
       "s_cbranch_scc1 PROBE_LOOP_%=\\n"
       "v_add_u32 %0, v0, v1\\n"
-      : "=v"(res) : "s"(iters) : {clob}, "s20", "scc", "vcc", "memory");
+      : "=v"(res) : "s"(iters) : {clob}, "s20", "s22", "s23", "s24", "s25", "scc", "vcc", "memory");
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * blockDim.x + threadIdx.x] = res;
   if (threadIdx.x == 0) st[blockIdx.x] = t1 - t0;
@@ -191,7 +221,7 @@ def main():
         body = single(op)
         name = "k_" + op
         src.append(kernel(name, body, len(body)))
-        ks.append((op, name, len(body) * (2 if op == "v_pk_fma_f32" else 1), 0))
+        ks.append((op, name, len(body), 0))
     for s in SCHEDS:
         body = sched(s)
         nv = sum(1 for l in body if l.startswith("v_"))
@@ -211,7 +241,7 @@ int main() {{
   hipEvent_t e0, e1; HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
   Entry ks[] = {{
     {table}}};
-  printf("device CUs=%d; Tlane-op/s = VALU lane-operations per second chip-wide (wall time of 10 launches); rows/s in 1e9 (64 queries x 1 train row = 64 compares)\\n", cus);
+  printf("device CUs=%d; T = 1e12 lane-instructions per second chip-wide (a packed or 64-bit instruction counts once per lane) (wall time of 10 launches); rows/s in 1e9 (64 queries x 1 train row = 64 compares)\\n", cus);
   for (int i = 0; i < 40; ++i) hipLaunchKernelGGL(ks[0].k, dim3(cus * 8), dim3(256), 0, 0, out, st, iters);
   HIPCHECK(hipDeviceSynchronize());
   const int ws[] = {{2, 4, 5, 8}};   // waves per SIMD resident (100 VGPRs allow 5; 8 only with fewer)
