@@ -24,6 +24,25 @@ def _run(q, t):
     return i.cpu().numpy(), d.cpu().numpy()
 
 
+def _knn2_raw(dq, q_off, nq, dt, t_off, nt, desc_bytes, stride):
+    """slamhip_hamming_knn2 through ctypes on raw device byte buffers: rows start
+    `*_off` bytes into the buffers and are `stride` bytes apart."""
+    import ctypes as C
+    from slam_amd import _lib
+    idx2 = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+    dist2 = torch.full((nq, 2), -7, dtype=torch.int32, device="cuda")
+    need = _lib.lib.slamhip_hamming_knn2_workspace_bytes(nq, nt, 1, nq, nt, desc_bytes)
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device="cuda")
+    rc = _lib.lib.slamhip_hamming_knn2(C.c_void_p(dq.data_ptr() + q_off), nq,
+                                       C.c_void_p(dt.data_ptr() + t_off), nt, desc_bytes, stride,
+                                       C.c_void_p(idx2.data_ptr()), C.c_void_p(dist2.data_ptr()),
+                                       C.c_void_p(ws.data_ptr()), C.c_size_t(need),
+                                       C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0, rc
+    torch.cuda.synchronize()
+    return idx2.cpu().numpy(), dist2.cpu().numpy()
+
+
 def test_library_loaded_is_in_tree():
     from slam_amd import _lib
     assert _lib.LIB_PATH.endswith("slam_amd/libslamhip.so")
@@ -111,6 +130,53 @@ def test_every_train_row_count_through_the_tile_scan(desc_bytes):
         ei, ed = so.hamming_knn2(qs[p], ts[p])
         np.testing.assert_array_equal(i[q_off[p]:q_off[p + 1]], ei, err_msg=f"{n} train rows")
         np.testing.assert_array_equal(d[q_off[p]:q_off[p + 1]], ed, err_msg=f"{n} train rows")
+
+
+def test_seeded_random_shapes_strides_and_knobs():
+    """Sixty seeded random cases through the C ABI: row counts 0..700, descriptor sizes
+    1..128 bytes, rows at random byte offsets and strides, a random number of train
+    splits and block size, single and batched calls; indices and distances equal the
+    NumPy restatement exactly."""
+    from slam_amd import _lib, kernels
+    rng = np.random.default_rng(20240611)
+    try:
+        for case in range(60):
+            d = int(rng.choice([1, 7, 16, 31, 32, 33, 61, 64, 65, 100, 128]))
+            _lib.lib.slamhip_tune(1, int(rng.choice([0, 1, 2, 7, 64])))
+            _lib.lib.slamhip_tune(3, int(rng.choice([0, 128, 256])))
+            n_pairs = int(rng.choice([1, 1, 3, 6]))
+            nqs = [int(rng.integers(0, 700)) for _ in range(n_pairs)]
+            nts = [int(rng.integers(0, 700)) for _ in range(n_pairs)]
+            hi = int(rng.choice([2, 4, 256]))          # few byte values -> many equal distances
+            qs = [rng.integers(0, hi, (n, d), dtype=np.uint8) for n in nqs]
+            ts = [rng.integers(0, hi, (n, d), dtype=np.uint8) for n in nts]
+            if n_pairs == 1:
+                stride = d + int(rng.integers(0, 9))
+                off = int(rng.integers(0, 5))
+
+                def strided(a):
+                    # the buffer ends exactly at the last row's last byte
+                    n = len(a)
+                    buf = rng.integers(0, 256, off + (max(n, 1) - 1) * stride + d, dtype=np.uint8)
+                    for r in range(n):
+                        buf[off + r * stride: off + r * stride + d] = a[r]
+                    return torch.from_numpy(buf).cuda()
+                i, dd = _knn2_raw(strided(qs[0]), off, nqs[0], strided(ts[0]), off, nts[0], d, stride)
+                ei, ed = so.hamming_knn2(qs[0], ts[0])
+                np.testing.assert_array_equal(i, ei, err_msg=f"case {case}: {nqs[0]}x{nts[0]}x{d} stride {stride}")
+                np.testing.assert_array_equal(dd, ed, err_msg=f"case {case}")
+            else:
+                q_off = np.concatenate([[0], np.cumsum(nqs)]).astype(np.int32)
+                t_off = np.concatenate([[0], np.cumsum(nts)]).astype(np.int32)
+                i, dd = kernels.hamming_knn2_batched(np.vstack(qs), np.vstack(ts), q_off, t_off)
+                i, dd = i.cpu().numpy(), dd.cpu().numpy()
+                for p in range(n_pairs):
+                    ei, ed = so.hamming_knn2(qs[p], ts[p])
+                    np.testing.assert_array_equal(i[q_off[p]:q_off[p + 1]], ei, err_msg=f"case {case} pair {p} D={d}")
+                    np.testing.assert_array_equal(dd[q_off[p]:q_off[p + 1]], ed, err_msg=f"case {case} pair {p}")
+    finally:
+        _lib.lib.slamhip_tune(1, 0)
+        _lib.lib.slamhip_tune(3, 0)
 
 
 def test_empty_inputs():
