@@ -395,26 +395,28 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
   }
 }
 
-// Folds the per-split key pairs.  Block = 16 query rows x 16 split groups: lane
-// (row, g) folds splits g, g+16, ... (16 rows x 8 bytes = one 128-byte line per
-// split), the sixteen groups meet in LDS and lane (row, 0) folds them in split order
-// of the groups.  Many small blocks: the fold is latency-bound, and 64-row blocks
-// left half of the CUs without work for 8192 rows.  Optionally applies the ratio
-// test to the final pair.
-constexpr int kMergeRows = 16, kMergeGroups = 16;
-
+// Folds the per-split key pairs.  Block = ROWS query rows x GROUPS split groups
+// (ROWS * GROUPS = 256): lane (row, g) folds splits g, g+GROUPS, ... (consecutive
+// rows: coalesced 8-byte entries), the groups meet in LDS and lane (row, 0) folds
+// them.  The keys are unique, so the order of the fold does not matter.  Many splits
+// (a single large pair: 64 splits of 8192 rows) take 16 x 16 - the fold is latency-
+// bound and 64-row blocks left half of the CUs without work; few splits over many
+// rows (a batch of frames) take 64 x 4 so that no group idles.  Optionally applies
+// the ratio test to the final pair.
+template <int ROWS, int GROUPS>
 __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restrict__ partial,
                                                             int nq_total, int n_splits,
                                                             int32_t *__restrict__ idx2,
                                                             int32_t *__restrict__ dist2,
                                                             double ratio,
                                                             uint8_t *__restrict__ keep) {
-  __shared__ uint2 part[kMergeGroups][kMergeRows];
-  const int lane = threadIdx.x % kMergeRows, g = threadIdx.x / kMergeRows;
-  const int row = blockIdx.x * kMergeRows + lane;
+  static_assert(ROWS * GROUPS == 256, "one thread per (row, group)");
+  __shared__ uint2 part[GROUPS][ROWS];
+  const int lane = threadIdx.x % ROWS, g = threadIdx.x / ROWS;
+  const int row = blockIdx.x * ROWS + lane;
   uint32_t b1 = kNoKey, b2 = kNoKey;
   if (row < nq_total) {
-    for (int s = g; s < n_splits; s += kMergeGroups) {
+    for (int s = g; s < n_splits; s += GROUPS) {
       const uint2 p = partial[(size_t)s * nq_total + row];
       top2_push(b1, b2, p.x);
       top2_push(b1, b2, p.y);
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restr
   __syncthreads();
   if (g != 0 || row >= nq_total) return;
 #pragma unroll
-  for (int k = 1; k < kMergeGroups; ++k) {
+  for (int k = 1; k < GROUPS; ++k) {
     const uint2 p = part[k][lane];
     top2_push(b1, b2, p.x);
     top2_push(b1, b2, p.y);
@@ -738,8 +740,12 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.splits > 1) {
-    hipLaunchKernelGGL(hamming_merge_kernel, dim3(slamhip_ceil_div(n_out_total, kMergeRows)), dim3(256), 0,
-                       st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
+    if (p.splits >= 16)
+      hipLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
+                         0, st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
+    else
+      hipLaunchKernelGGL((hamming_merge_kernel<64, 4>), dim3(slamhip_ceil_div(n_out_total, 64)), dim3(256),
+                         0, st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
     SLAMHIP_CHECK_LAUNCH();
   } else if (d_keep != nullptr) {
     hipLaunchKernelGGL(ratio_test_kernel, dim3(slamhip_ceil_div(n_out_total, 256)), dim3(256), 0, st,
