@@ -47,7 +47,8 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
-         hipStream_t st, const int32_t *d_out_off = nullptr, int n_out_total = -1);
+         hipStream_t st, const int32_t *d_out_off = nullptr, int n_out_total = -1,
+         bool best_only = false);   // best_only: second-best entries come back as -1
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,

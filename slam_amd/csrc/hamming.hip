@@ -96,46 +96,54 @@ __device__ __forceinline__ void top2_push(uint32_t &b1, uint32_t &b2, uint32_t k
   "v_med3_u32 %1, %0, %1, v" #r "\n"                                                            \
   "v_min_u32 %0, %0, v" #r "\n"
 #define SLAMHIP_PUSH SLAMHIP_PUSH_R(62)
+// best match only (k = 1 callers): no second-best update
+#define SLAMHIP_PUSH1_R(r)                                                                      \
+  "v_lshl_or_b32 v" #r ", v" #r ", 21, %3\n"                                                    \
+  "v_min_u32 %0, %0, v" #r "\n"
+#define SLAMHIP_PUSH1 SLAMHIP_PUSH1_R(62)
 #define SLAMHIP_SCAN_CLOBBERS                                                                   \
   "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42",     \
   "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55",     \
   "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "scc", "memory"
 
-__device__ __forceinline__ void scan_tile16(uint32_t lds_addr, int rows, uint32_t key0,
-                                            const uint32_t (&q)[16], uint32_t &b1, uint32_t &b2) {
-  asm volatile(
-      "v_mov_b32 v63, %4\n"
-      SLAMHIP_LD_A(0, 16, 32, 48)
-      "s_cmp_lt_u32 %2, 2\n"
-      "s_cbranch_scc1 SCAN_TAIL_%=\n"
-      "SCAN_LOOP_%=:\n"
-      SLAMHIP_LD_B(64, 80, 96, 112)
-      "s_waitcnt lgkmcnt(4)\n"
-      SLAMHIP_DIST_A
-      SLAMHIP_PUSH
-      "v_add_u32 v63, 0x80, v63\n"
-      SLAMHIP_LD_A(0, 16, 32, 48)
-      "s_add_u32 %3, %3, 1\n"
-      "s_waitcnt lgkmcnt(4)\n"
-      SLAMHIP_DIST_B
-      SLAMHIP_PUSH
-      "s_add_u32 %3, %3, 1\n"
-      "s_sub_u32 %2, %2, 2\n"
-      "s_cmp_lt_u32 %2, 2\n"
-      "s_cbranch_scc0 SCAN_LOOP_%=\n"
-      "SCAN_TAIL_%=:\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      "s_cmp_eq_u32 %2, 0\n"
-      "s_cbranch_scc1 SCAN_DONE_%=\n"
-      SLAMHIP_DIST_A
-      SLAMHIP_PUSH
-      "SCAN_DONE_%=:\n"
-      : "+v"(b1), "+v"(b2), "+s"(rows), "+s"(key0)
-      : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]),
-        "v"(q[7]), "v"(q[8]), "v"(q[9]), "v"(q[10]), "v"(q[11]), "v"(q[12]), "v"(q[13]), "v"(q[14]),
-        "v"(q[15])
-      : SLAMHIP_SCAN_CLOBBERS);
+#define SLAMHIP_DEFINE_SCAN16(NAME, PUSHM) \
+__device__ __forceinline__ void NAME(uint32_t lds_addr, int rows, uint32_t key0, \
+                                            const uint32_t (&q)[16], uint32_t &b1, uint32_t &b2) { \
+  asm volatile( \
+      "v_mov_b32 v63, %4\n" \
+      SLAMHIP_LD_A(0, 16, 32, 48) \
+      "s_cmp_lt_u32 %2, 2\n" \
+      "s_cbranch_scc1 SCAN_TAIL_%=\n" \
+      "SCAN_LOOP_%=:\n" \
+      SLAMHIP_LD_B(64, 80, 96, 112) \
+      "s_waitcnt lgkmcnt(4)\n" \
+      SLAMHIP_DIST_A \
+      PUSHM \
+      "v_add_u32 v63, 0x80, v63\n" \
+      SLAMHIP_LD_A(0, 16, 32, 48) \
+      "s_add_u32 %3, %3, 1\n" \
+      "s_waitcnt lgkmcnt(4)\n" \
+      SLAMHIP_DIST_B \
+      PUSHM \
+      "s_add_u32 %3, %3, 1\n" \
+      "s_sub_u32 %2, %2, 2\n" \
+      "s_cmp_lt_u32 %2, 2\n" \
+      "s_cbranch_scc0 SCAN_LOOP_%=\n" \
+      "SCAN_TAIL_%=:\n" \
+      "s_waitcnt lgkmcnt(0)\n" \
+      "s_cmp_eq_u32 %2, 0\n" \
+      "s_cbranch_scc1 SCAN_DONE_%=\n" \
+      SLAMHIP_DIST_A \
+      PUSHM \
+      "SCAN_DONE_%=:\n" \
+      : "+v"(b1), "+v"(b2), "+s"(rows), "+s"(key0) \
+      : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), \
+        "v"(q[7]), "v"(q[8]), "v"(q[9]), "v"(q[10]), "v"(q[11]), "v"(q[12]), "v"(q[13]), "v"(q[14]), \
+        "v"(q[15]) \
+      : SLAMHIP_SCAN_CLOBBERS); \
 }
+SLAMHIP_DEFINE_SCAN16(scan_tile16, SLAMHIP_PUSH)
+SLAMHIP_DEFINE_SCAN16(scan_tile16_best, SLAMHIP_PUSH1)
 
 // The same for 8-word rows (descriptors of at most 32 bytes): a buffer holds two
 // consecutive rows, compared as 16 xors and two popcount chains (the second one
@@ -151,50 +159,53 @@ __device__ __forceinline__ void scan_tile16(uint32_t lds_addr, int rows, uint32_
   SLAMHIP_BC_(acc, base, 1) SLAMHIP_BC_(acc, base, 2) SLAMHIP_BC_(acc, base, 3)                 \
   SLAMHIP_BC_(acc, base, 4) SLAMHIP_BC_(acc, base, 5) SLAMHIP_BC_(acc, base, 6) SLAMHIP_BC_(acc, base, 7)
 // two rows of a buffer starting at register `lo` (second row at `hi` = lo + 8)
-#define SLAMHIP_DIST8X2(lo, hi)                                                                 \
+#define SLAMHIP_DIST8X2(lo, hi, P)                                                              \
   SLAMHIP_XR8(lo) SLAMHIP_XR8(hi) SLAMHIP_CHAIN8(62, lo) SLAMHIP_CHAIN8(hi, hi)                 \
-  SLAMHIP_PUSH_R(62) "s_add_u32 %3, %3, 1\n" SLAMHIP_PUSH_R(hi) "s_add_u32 %3, %3, 1\n"
-#define SLAMHIP_DIST8X1(lo)                                                                     \
-  SLAMHIP_XR8(lo) SLAMHIP_CHAIN8(62, lo) SLAMHIP_PUSH_R(62) "s_add_u32 %3, %3, 1\n"
+  P(62) "s_add_u32 %3, %3, 1\n" P(hi) "s_add_u32 %3, %3, 1\n"
+#define SLAMHIP_DIST8X1(lo, P)                                                                  \
+  SLAMHIP_XR8(lo) SLAMHIP_CHAIN8(62, lo) P(62) "s_add_u32 %3, %3, 1\n"
 
-__device__ __forceinline__ void scan_tile8(uint32_t lds_addr, int rows, uint32_t key0,
-                                           const uint32_t (&q)[8], uint32_t &b1, uint32_t &b2) {
-  asm volatile(
-      "v_mov_b32 v63, %4\n"
-      SLAMHIP_LD_A(0, 16, 32, 48)
-      "s_cmp_lt_u32 %2, 4\n"
-      "s_cbranch_scc1 SCAN_TAIL_%=\n"
-      "SCAN_LOOP_%=:\n"
-      SLAMHIP_LD_B(64, 80, 96, 112)
-      "s_waitcnt lgkmcnt(4)\n"
-      SLAMHIP_DIST8X2(30, 38)
-      "v_add_u32 v63, 0x80, v63\n"
-      SLAMHIP_LD_A(0, 16, 32, 48)
-      "s_waitcnt lgkmcnt(4)\n"
-      SLAMHIP_DIST8X2(46, 54)
-      "s_sub_u32 %2, %2, 4\n"
-      "s_cmp_lt_u32 %2, 4\n"
-      "s_cbranch_scc0 SCAN_LOOP_%=\n"
-      "SCAN_TAIL_%=:\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      "s_cmp_eq_u32 %2, 0\n"
-      "s_cbranch_scc1 SCAN_DONE_%=\n"
-      SLAMHIP_DIST8X1(30)
-      "s_cmp_eq_u32 %2, 1\n"
-      "s_cbranch_scc1 SCAN_DONE_%=\n"
-      SLAMHIP_DIST8X1(38)
-      "s_cmp_eq_u32 %2, 2\n"
-      "s_cbranch_scc1 SCAN_DONE_%=\n"
-      "ds_read_b128 v[46:49], v63 offset:64\n"
-      "ds_read_b128 v[50:53], v63 offset:80\n"
-      "s_waitcnt lgkmcnt(0)\n"
-      SLAMHIP_DIST8X1(46)
-      "SCAN_DONE_%=:\n"
-      : "+v"(b1), "+v"(b2), "+s"(rows), "+s"(key0)
-      : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]),
-        "v"(q[7])
-      : SLAMHIP_SCAN_CLOBBERS);
+#define SLAMHIP_DEFINE_SCAN8(NAME, P) \
+__device__ __forceinline__ void NAME(uint32_t lds_addr, int rows, uint32_t key0, \
+                                           const uint32_t (&q)[8], uint32_t &b1, uint32_t &b2) { \
+  asm volatile( \
+      "v_mov_b32 v63, %4\n" \
+      SLAMHIP_LD_A(0, 16, 32, 48) \
+      "s_cmp_lt_u32 %2, 4\n" \
+      "s_cbranch_scc1 SCAN_TAIL_%=\n" \
+      "SCAN_LOOP_%=:\n" \
+      SLAMHIP_LD_B(64, 80, 96, 112) \
+      "s_waitcnt lgkmcnt(4)\n" \
+      SLAMHIP_DIST8X2(30, 38, P) \
+      "v_add_u32 v63, 0x80, v63\n" \
+      SLAMHIP_LD_A(0, 16, 32, 48) \
+      "s_waitcnt lgkmcnt(4)\n" \
+      SLAMHIP_DIST8X2(46, 54, P) \
+      "s_sub_u32 %2, %2, 4\n" \
+      "s_cmp_lt_u32 %2, 4\n" \
+      "s_cbranch_scc0 SCAN_LOOP_%=\n" \
+      "SCAN_TAIL_%=:\n" \
+      "s_waitcnt lgkmcnt(0)\n" \
+      "s_cmp_eq_u32 %2, 0\n" \
+      "s_cbranch_scc1 SCAN_DONE_%=\n" \
+      SLAMHIP_DIST8X1(30, P) \
+      "s_cmp_eq_u32 %2, 1\n" \
+      "s_cbranch_scc1 SCAN_DONE_%=\n" \
+      SLAMHIP_DIST8X1(38, P) \
+      "s_cmp_eq_u32 %2, 2\n" \
+      "s_cbranch_scc1 SCAN_DONE_%=\n" \
+      "ds_read_b128 v[46:49], v63 offset:64\n" \
+      "ds_read_b128 v[50:53], v63 offset:80\n" \
+      "s_waitcnt lgkmcnt(0)\n" \
+      SLAMHIP_DIST8X1(46, P) \
+      "SCAN_DONE_%=:\n" \
+      : "+v"(b1), "+v"(b2), "+s"(rows), "+s"(key0) \
+      : "v"(lds_addr), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), \
+        "v"(q[7]) \
+      : SLAMHIP_SCAN_CLOBBERS); \
 }
+SLAMHIP_DEFINE_SCAN8(scan_tile8, SLAMHIP_PUSH_R)
+SLAMHIP_DEFINE_SCAN8(scan_tile8_best, SLAMHIP_PUSH1_R)
 
 // ---------------------------------------------------------------------------
 // Row packing: (n, desc_bytes) rows `stride` bytes apart -> (n, W) dwords,
@@ -240,7 +251,9 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(
 // ---------------------------------------------------------------------------
 // Main kernel.
 // ---------------------------------------------------------------------------
-template <int W, int Q, bool USE_LDS, int T = kThreads>
+// BEST: only the best match per query is wanted (k = 1 callers); the hand-scheduled
+// scans then skip the second-best update and the second key stays "none".
+template <int W, int Q, bool USE_LDS, int T = kThreads, bool BEST = false>
 __global__ __launch_bounds__(T) void hamming_top2_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
@@ -304,7 +317,9 @@ __global__ __launch_bounds__(T) void hamming_top2_kernel(
         const uint32_t lds_addr =
             (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)tile;
         const uint32_t key0 = (uint32_t)__builtin_amdgcn_readfirstlane(tile_begin);
-        if constexpr (W == 16) scan_tile16(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
+        if constexpr (W == 16 && BEST) scan_tile16_best(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
+        else if constexpr (W == 16) scan_tile16(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
+        else if constexpr (BEST) scan_tile8_best(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
         else scan_tile8(lds_addr, rows_u, key0, qv[0], b1[0], b2[0]);
       } else {
       int jj = 0;
@@ -654,12 +669,12 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   return p;
 }
 
-template <int W, int Q, bool L, int T = kThreads>
+template <int W, int Q, bool L, int T = kThreads, bool BEST = false>
 void launch_top2(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp,
                  const int32_t *q_off, const int32_t *q_cnt, const int32_t *t_off,
                  const int32_t *t_cnt, const int32_t *out_off, int nq, int nt, int nq_total,
                  uint2 *part, int32_t *idx2, int32_t *dist2) {
-  hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L, T>), grid, dim3(T), 0, st, qp, tp, q_off, q_cnt,
+  hipLaunchKernelGGL((hamming_top2_kernel<W, Q, L, T, BEST>), grid, dim3(T), 0, st, qp, tp, q_off, q_cnt,
                      t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2);
 }
 
@@ -669,7 +684,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
              void *d_workspace, size_t workspace_bytes, void *stream, bool prepacked = false,
              const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr,
              uint8_t *d_keep = nullptr, double ratio = 0.0, const int32_t *d_out_off = nullptr,
-             int n_out_total = -1) {
+             int n_out_total = -1, bool best_only = false) {
   if (n_out_total < 0) n_out_total = nq_total;
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
     return SLAMHIP_EINVAL;
@@ -721,7 +736,13 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 #define SLAMHIP_DISPATCH_HALF(WW)                                                                  \
   launch_top2<WW, 1, true, kThreads / 2>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt,     \
                                          d_out_off, nqs, nts, n_out_total, part, d_idx2, d_dist2)
-  if (p.threads == kThreads / 2) {
+#define SLAMHIP_DISPATCH_BEST(WW, TT)                                                              \
+  launch_top2<WW, 1, true, TT, true>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, d_out_off, \
+                                     nqs, nts, n_out_total, part, d_idx2, d_dist2)
+  if (best_only && p.use_lds && p.Q == 1 && p.W <= 16) {
+    if (p.threads == kThreads / 2) { if (p.W == 8) SLAMHIP_DISPATCH_BEST(8, kThreads / 2); else SLAMHIP_DISPATCH_BEST(16, kThreads / 2); }
+    else                           { if (p.W == 8) SLAMHIP_DISPATCH_BEST(8, kThreads); else SLAMHIP_DISPATCH_BEST(16, kThreads); }
+  } else if (p.threads == kThreads / 2) {
     if (p.W == 8) SLAMHIP_DISPATCH_HALF(8);
     else if (p.W == 16) SLAMHIP_DISPATCH_HALF(16);
     else SLAMHIP_DISPATCH_HALF(32);
@@ -736,6 +757,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   }
 #undef SLAMHIP_DISPATCH
 #undef SLAMHIP_DISPATCH_HALF
+#undef SLAMHIP_DISPATCH_BEST
   if (ev) (void)hipEventRecord(ev->second, st);
   SLAMHIP_CHECK_LAUNCH();
 
@@ -926,10 +948,10 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
-         hipStream_t st, const int32_t *d_out_off, int n_out_total) {
+         hipStream_t st, const int32_t *d_out_off, int n_out_total, bool best_only) {
   return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
                   n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, (void *)st,
-                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total);
+                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total, best_only);
 }
 
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,

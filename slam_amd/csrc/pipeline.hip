@@ -757,7 +757,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
     rc = slamhip_internal::knn2((const uint8_t *)packL, a->n_left_total, (const uint8_t *)packR,
                                 a->n_right_total, a->desc_bytes, W * 4, true, a->d_off_left, nullptr,
                                 a->d_off_right, nullptr, F, a->max_left, a->max_right, idx2, dist2,
-                                knn_ws, L.knn_bytes, st);
+                                knn_ws, L.knn_bytes, st, nullptr, -1, true);
     if (rc) return rc;
   } else {
     if (hipMemsetAsync(bid, 0xFF, sizeof(uint32_t) * (size_t)a->n_left_total, st) != hipSuccess)
@@ -766,7 +766,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
       rc = slamhip_internal::knn2((const uint8_t *)packR, a->n_right_total, (const uint8_t *)packL,
                                   a->n_left_total, a->desc_bytes, W * 4, true, a->d_off_right, nullptr,
                                   a->d_off_left, nullptr, F, a->max_right, a->max_left, ridx2, rdist2,
-                                  knn_ws, L.knn_bytes, st);
+                                  knn_ws, L.knn_bytes, st, nullptr, -1, true);
       if (rc) return rc;
       hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_right, kBlock), F), dim3(kBlock),
                          0, st, a->d_off_right, (const int32_t *)nullptr, a->d_off_left, ridx2, rdist2,
@@ -796,7 +796,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                                 (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
                                 true, a->d_off_left, a->d_st_count, a->d_off_left + 1,
                                 a->d_st_count + 1, F - 1, a->max_left, a->max_left, tidx2, tdist2, knn_ws,
-                                L.knn_bytes, st);
+                                L.knn_bytes, st, nullptr, -1, true);
     if (rc) return rc;
   } else {
     // the inliers of frame p+1 choose among those of frame p, then bid for them
@@ -806,7 +806,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                                 (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
                                 true, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left,
                                 a->d_st_count, F - 1, a->max_left, a->max_left, ridx2, rdist2, knn_ws,
-                                L.knn_bytes, st);
+                                L.knn_bytes, st, nullptr, -1, true);
     if (rc) return rc;
     hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F - 1), dim3(kBlock),
                        0, st, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left, ridx2, rdist2, bid);
@@ -929,7 +929,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
     rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
                                 a->n_rows_total, a->desc_bytes, W * 4, true, qb, qc, tb, tc, np,
                                 a->max_q, a->max_t, idx2, dist2, knn_ws, knn_bytes, st, ob,
-                                a->n_out_total);
+                                a->n_out_total, true);
     if (rc) return rc;
     rc = slamhip_internal::sort_by_distance(dist2, 2, ob, qc, np, a->max_q, order, st);
     if (rc) return rc;
