@@ -26,6 +26,38 @@ from ... import kernels
 Frame = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]
 
 
+# ---------------------------------------------------------------- host staging
+# Page-locked staging buffers of `upload`, kept for the life of the process and
+# grown on demand: allocating ~100 MB of page-locked memory costs several times the
+# whole pass.  One event marks the last asynchronous copy out of them; the next
+# upload waits for it before it overwrites them.  Not thread-safe: one uploader at a
+# time.  (Filling them from several threads was measured slower on the GPU box's
+# share of host cores: 5.6 ms with one thread, 9-12 ms with four or eight, for the
+# 104 MB of 500 frames.)
+_stage_bufs: dict = {}
+_stage_event = None
+
+
+def _staging(slot: int, dtype: torch.dtype, numel: int) -> torch.Tensor:
+    buf = _stage_bufs.get(slot)
+    if buf is None or buf.dtype != dtype or buf.numel() < numel:
+        buf = torch.empty(max(int(numel * 1.25), 1), dtype=dtype, pin_memory=True)
+        _stage_bufs[slot] = buf
+    return buf[:numel]
+
+
+def _staging_wait():
+    if _stage_event is not None:
+        _stage_event.synchronize()
+
+
+def _staging_mark():
+    global _stage_event
+    if _stage_event is None:
+        _stage_event = torch.cuda.Event()
+    _stage_event.record(torch.cuda.current_stream())
+
+
 @dataclass
 class FrontendInputs:
     """Concatenated, device-resident inputs of a run of frames."""
@@ -134,20 +166,23 @@ class TrackingFrontend:
         device = kernels.to_device(off_l, torch.int32).device
 
         def cat(i, np_dt, t_dt, w, total):
-            # concatenated straight into a page-locked buffer, then one asynchronous copy
-            # (torch keeps the buffer until the copy has run)
-            stage = torch.empty((total, w), dtype=t_dt, pin_memory=True)
+            # concatenated straight into a page-locked staging buffer, then one
+            # asynchronous copy
+            stage = _staging(i, t_dt, total * w).view(total, w)
             if total:
                 np.concatenate([np.asarray(f[i], dtype=np_dt).reshape(-1, w) for f in frames],
                                out=stage.numpy())
             return stage.to(device, non_blocking=True)
 
+        _staging_wait()
         dev = kernels.to_device
-        return FrontendInputs(len(frames), off_l, off_r, dev(off_l, torch.int32), dev(off_r, torch.int32),
-                              cat(0, np.float32, torch.float32, 2, int(off_l[-1])),
-                              cat(1, np.float32, torch.float32, 2, int(off_r[-1])),
-                              cat(2, np.uint8, torch.uint8, d, int(off_l[-1])),
-                              cat(3, np.uint8, torch.uint8, d, int(off_r[-1])))
+        inputs = FrontendInputs(len(frames), off_l, off_r, dev(off_l, torch.int32), dev(off_r, torch.int32),
+                                cat(0, np.float32, torch.float32, 2, int(off_l[-1])),
+                                cat(1, np.float32, torch.float32, 2, int(off_r[-1])),
+                                cat(2, np.uint8, torch.uint8, d, int(off_l[-1])),
+                                cat(3, np.uint8, torch.uint8, d, int(off_r[-1])))
+        _staging_mark()
+        return inputs
 
     # ---------------------------------------------------------------------- run
     def run(self, frames_or_inputs, samples: Optional[np.ndarray] = None) -> FrontendResult:
