@@ -53,14 +53,14 @@ def peak_compares_per_sec(desc_bytes):
 
 
 PEAK_LANE_OPS = peak_compares_per_sec(DESC_BYTES) * 2 * ((DESC_BYTES + 3) // 4)   # 52.4 T for 61 B
-# HBM-side bytes per top-2 launch from the committed PMC passes (profiles/r1/pmc_matcher8k.txt):
-# FETCH_SIZE 2327 KB x2 (gfx950 wide-read correction) + WRITE_SIZE 4096 KB.
-PMC_TRAFFIC_BYTES = (2327 * 2 + 4096) * 1024
+# HBM-side bytes per top-2 launch from the committed PMC passes (profiles/r1/pmc_matcher8k_p.txt):
+# FETCH_SIZE 2325 KB x2 (gfx950 wide-read correction) + WRITE_SIZE 4096 KB.
+PMC_TRAFFIC_BYTES = (2325 * 2 + 4096) * 1024
 OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
 HBM_BYTES_PER_CALL = (NQ + NT) * DESC_BYTES + NQ * 16 + NQ   # read descriptors, write idx2/dist2/keep
 
 
-def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 1.5):
+def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 10.0):
     """Times the CPU port (C + OpenMP, all host threads OpenMP gives us)."""
     path = os.path.join(ROOT, "oracle", "liboracle.so")
     if not os.path.exists(path):
@@ -81,7 +81,7 @@ def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 1.5):
     t0 = time.perf_counter()
     once()
     one = time.perf_counter() - t0
-    reps = max(1, min(50, int(target_s / max(one, 1e-6))))
+    reps = max(1, min(2000, int(target_s / max(one, 1e-6))))
     t0 = time.perf_counter()
     for _ in range(reps):
         once()
@@ -199,7 +199,7 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
                            "temporal_matches_mean": float(i2[:, 5].mean()),
                            "ransac_iterations_mean": float(i2[:, 2].mean())}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_frontend(cam, frames[:7])
+        out["cpu_baseline"] = cpu_baseline_frontend(cam, frames[:41])
         out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     return out
 
@@ -441,7 +441,7 @@ def main():
                          "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
                          "traffic": PMC_TRAFFIC_BYTES,
                          "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes "
-                                         "(profiles/r1/pmc_matcher8k.txt); includes the 4 MB of "
+                                         "(profiles/r1/pmc_matcher8k_p.txt); includes the 4 MB of "
                                          "split results the kernel writes for the merge"},
         }
         if world == 1 and not args.no_sweep:
