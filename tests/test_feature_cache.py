@@ -55,3 +55,21 @@ def test_gaps_and_missing_directory(tmp_path):
     (tmp_path / "empty").mkdir()
     with pytest.raises(FileNotFoundError):
         fc.FeatureCache(str(tmp_path / "empty"))
+
+
+def test_extractor_script_says_what_it_needs_without_opencv(tmp_path):
+    """tools/extract_features.py is the one place that imports cv2; where OpenCV is not
+    installed it stops with a message instead of a traceback."""
+    import importlib.util
+    import os
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV is installed here")
+    except ImportError:
+        pass
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("extract_features", os.path.join(root, "tools", "extract_features.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    with pytest.raises(SystemExit, match="OpenCV"):
+        mod.main(["--data", str(tmp_path), "--out", str(tmp_path / "cache")])
