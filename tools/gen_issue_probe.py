@@ -53,6 +53,9 @@ OPS = {
     "v_cvt_f32_ubyte0": "v_cvt_f32_ubyte0 {d}, {a}",
     # lane-mask consumers and producers (the consensus-counting loop)
     "v_cndmask_sgpr":   "v_cndmask_b32_e64 {d}, {a}, {d}, s[22:23]",
+    "v_cndmask_vcc_e64": "v_cndmask_b32_e64 {d}, {a}, {d}, vcc",
+    "v_cndmask_2src":   "v_cndmask_b32_e32 {d}, {a}, {b}, vcc",
+    "v_cmp_then_cnd":   "v_cmp_lt_f32 vcc, {a}, {b}\\nv_cndmask_b32_e32 {d}, {a}, {d}, vcc",
     "v_cndmask_imm":    "v_cndmask_b32_e64 {d}, 0, 1, s[22:23]",
     "v_addc_vcc":       "v_addc_co_u32 {d}, vcc, 0, {d}, vcc",
     "v_addc_sgpr":      "v_addc_co_u32_e64 {d}, s[24:25], 0, {d}, s[22:23]",
@@ -196,6 +199,7 @@ __global__ __launch_bounds__(256) void {name}(uint32_t *out, unsigned long long 
       "v_mov_b32 {addr}, 0\\n"
       "s_mov_b32 s20, %1\\n"
       "s_mov_b32 s22, 0x55555555\\n"
+      "s_mov_b64 vcc, 0x33\\n"
       "s_mov_b32 s23, 0x33333333\\n"
       "PROBE_LOOP_%=:\\n"
       "{asm}\\n"
