@@ -439,6 +439,8 @@ def main():
                          "kernel_us": kernel_s * 1e6, "launches_timed": n_launch,
                          "frac_if_every_op_issued_in_2_cycles": achieved / UNIFORM_PEAK_LANE_OPS,
                          "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
+                         "hbm_peak_GBps": 8000.0,
+                         "hbm_frac": HBM_BYTES_PER_CALL / kernel_s / 8e12,
                          "traffic": PMC_TRAFFIC_BYTES,
                          "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes "
                                          "(profiles/r1/pmc_matcher8k_q.txt); includes the 4 MB of "
