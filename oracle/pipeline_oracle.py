@@ -1,8 +1,12 @@
 """
 CPU restatement of the per-frame data flow of TrackingPipeline.build()
 (backend/tracking/fill_database.py:102-240 of the reference), features given.
-TEST INFRASTRUCTURE ONLY (see oracle/slam_oracle.py for the pinning status of
-each step; the steps that live in OpenCV are parity unpinned).
+TEST INFRASTRUCTURE ONLY.  The data flow restated here is pinned against the
+reference's own TrackingPipeline.build() and LoopClosure.consensus_pnp_match(), run as
+they are with their OpenCV leaves standing on oracle/slam_oracle.py
+(oracle/make_golden_flow.py -> tests/golden/ref_build_flow.npz, ref_consensus_flow.npz,
+tests/test_reference_flow.py); the steps that live in OpenCV themselves are parity
+unpinned (see oracle/slam_oracle.py for the status of each).
 
 It is deliberately written the way the reference is: one frame at a time, one
 RANSAC iteration at a time, so that it also serves as the shape of the CPU

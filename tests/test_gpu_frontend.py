@@ -405,3 +405,39 @@ def test_front_end_call_captures_into_a_hip_graph():
     a, b = captured.pair(0), expect.pair(0)
     for k in b:
         np.testing.assert_array_equal(a[k], b[k], err_msg=f"pair {k}")
+
+
+def test_front_end_against_the_references_own_frame_loop(golden):
+    """tests/golden/ref_build_flow.npz: what the reference's TrackingPipeline.build()
+    handed to TrackingDB.add_frame and to its pose refinement when it ran, as it is, on
+    these frames (its OpenCV leaves on the CPU restatement, its RANSAC sampler seeded;
+    oracle/make_golden_flow.py).  The batched HIP front-end on the same frames, with the
+    same sample sequence: identical links, inlier descriptors and temporal matches; the
+    same RANSAC inliers and relative poses up to the minimal solver's rounding."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    g = golden("ref_build_flow.npz")
+    F, seed0 = int(g["n_frames"]), int(g["seed0"])
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    frames = [(g[f"kp_left_{k}"], g[f"kp_right_{k}"], g[f"des_left_{k}"], g[f"des_right_{k}"]) for k in range(F)]
+    n_iter = 2500
+    samples = np.zeros((F - 1, n_iter, 4), np.int32)
+    for p in range(F - 1):
+        rng = np.random.default_rng(seed0 + p)          # the generator the reference's loop drew from
+        N = len(g[f"tm_query_{p + 1}"])
+        for i in range(200):                            # far more than the loop consumed
+            samples[p, i] = rng.choice(N, 4, replace=False)
+    res = TrackingFrontend(cam, n_iter_max=n_iter).run(frames, samples=samples)
+    for k in range(F):
+        got = res.frame(k)
+        np.testing.assert_array_equal(got["links"], g[f"links_{k}"], err_msg=f"links of frame {k}")
+        np.testing.assert_array_equal(got["inlier_des_left"], g[f"inlier_des_{k}"])
+    for p in range(F - 1):
+        got = res.pair(p)
+        np.testing.assert_array_equal(got["query_idx"], g[f"tm_query_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(got["train_idx"], g[f"tm_train_{p + 1}"])
+        ref_mask = g[f"tm_mask_{p + 1}"]
+        assert got["iterations"] < 200
+        assert (got["mask"] != ref_mask).sum() <= 1, f"pair {p}: {(got['mask'] != ref_mask).sum()} points differ"
+        if (got["mask"] == ref_mask).all():
+            assert np.abs(got["Rt"] - g["relative_Rts"][p]).max() < 1e-6

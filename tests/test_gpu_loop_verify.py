@@ -101,3 +101,36 @@ def test_lazy_match_arrays_agree():
             np.testing.assert_array_equal(one[key], res[key][sl])
             np.testing.assert_array_equal(vm[key][vs], res[key][sl])
         assert one["mask"].dtype == bool and one["mask"].sum() == res["n_inliers"][p]
+
+
+def test_verify_against_the_references_own_consensus_check(golden):
+    """tests/golden/ref_consensus_flow.npz: outcomes of the reference's own
+    LoopClosure.consensus_pnp_match (run as it is, OpenCV leaves on the CPU restatement,
+    oracle/make_golden_flow.py) for a verified pair, a pair stopped at the first
+    `min_inliers_loop` gate and one stopped at the second.  The device draws other random
+    samples and the adaptive stop keeps the first hypothesis that is good enough, so the
+    consensus sets overlap without being equal (1.5 px threshold on 0.4 px noise); the
+    decision, the gates and the relative pose must agree."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    g = golden("ref_consensus_flow.npz")
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    ids = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("links_"))
+    keyframes = [(g[f"links_{k}"], g[f"des_{k}"]) for k in ids]
+    for i, (curr, cand, gate) in enumerate(g["cases"]):
+        ver = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i).set_keyframes(keyframes)
+        res = ver.verify(np.array([[ids.index(int(cand)), ids.index(int(curr))]], dtype=np.int64))
+        assert bool(res["ok"][0]) == bool(g[f"ok_{i}"]), f"case {i}"
+        if int(g[f"rng_calls_{i}"]) == 0:
+            assert res["iterations"][0] == 0              # first gate: RANSAC never ran
+        if not res["ok"][0]:
+            continue
+        sl = slice(int(res["out_off"][0]), int(res["out_off"][1]))
+        ref_mask = g[f"mask_{i}"]
+        assert len(res["mask"][sl]) == len(ref_mask)      # one match per candidate feature
+        assert res["mask"][sl].sum() >= gate and ref_mask.sum() >= gate
+        assert (res["mask"][sl] & ref_mask).sum() > 0.5 * ref_mask.sum()
+        T = np.eye(4)
+        T[:3] = res["Rt"][0]
+        D = np.linalg.inv(T) - g[f"delta_inv_{i}"]
+        assert np.abs(D[:3, :3]).max() < 5e-3 and np.abs(D[:3, 3]).max() < 0.15, D

@@ -1,0 +1,89 @@
+"""The restated data flow (oracle/pipeline_oracle.py) against the reference's own callers.
+
+tests/golden/ref_build_flow.npz and ref_consensus_flow.npz hold what the reference's
+TrackingPipeline.build() (backend/tracking/fill_database.py:85-255) and
+LoopClosure.consensus_pnp_match() (backend/optimizers/loop_closure.py:167-235) did when
+they were run as they are on small synthetic frames, with only their OpenCV leaves
+(BFMatcher.match, triangulatePoints, solvePnP) standing on the same CPU restatement
+this file uses and numpy.random.default_rng() seeded (oracle/make_golden_flow.py).
+What is pinned is therefore everything BETWEEN the leaves: which descriptors are
+matched against which, the stereo filter, the order of links and inlier descriptors
+handed to TrackingDB.add_frame, the 3-D / 2-D correspondences given to RANSAC, the
+RANSAC loop itself (iteration count, winner), the points given to the refinement, the
+two gates of the loop-closure check.
+"""
+import numpy as np
+import pytest
+
+from oracle import pipeline_oracle as po
+from oracle import slam_oracle as so
+
+
+class _Cam:
+    def __init__(self, P0, P1):
+        P0, P1 = np.asarray(P0, np.float64).reshape(3, 4), np.asarray(P1, np.float64).reshape(3, 4)
+        self.K = P0[:, :3].copy()
+        Kinv = np.linalg.inv(self.K)
+        self.M_left, self.M_right = Kinv @ P0, Kinv @ P1        # camera_model.py:59-73
+        self.P_left, self.P_right = self.K @ self.M_left, self.K @ self.M_right
+
+
+def test_frame_loop_equals_the_references_build(golden):
+    g = golden("ref_build_flow.npz")
+    cam = _Cam(g["P0"], g["P1"])
+    F, seed0 = int(g["n_frames"]), int(g["seed0"])
+    frames = [(g[f"kp_left_{k}"], g[f"kp_right_{k}"], g[f"des_left_{k}"], g[f"des_right_{k}"]) for k in range(F)]
+    stereo = [po.stereo_stage(cam, f, pixel_thresh=4.0, disparity_min=1.2) for f in frames]
+    for k, s in enumerate(stereo):
+        # Link(x_left, x_right, (y_left + y_right) / 2) in match order (database.py:268-277)
+        links = np.column_stack([s["pix_left"][:, 0].astype(np.float64), s["pix_right"][:, 0].astype(np.float64),
+                                 (s["pix_left"][:, 1].astype(np.float64) + s["pix_right"][:, 1].astype(np.float64)) / 2])
+        np.testing.assert_array_equal(links, g[f"links_{k}"], err_msg=f"links of frame {k}")
+        np.testing.assert_array_equal(s["inlier_des_left"], g[f"inlier_des_{k}"], err_msg=f"descriptors of frame {k}")
+    assert len(g["tm_query_0"]) == 0 and len(g["tm_mask_0"]) == 0          # frame 0 has no previous frame
+    for p in range(F - 1):
+        t = po.temporal_stage(cam, stereo[p], stereo[p + 1], pixel_thresh=4.0,
+                              rng=np.random.default_rng(seed0 + p))
+        np.testing.assert_array_equal(t["query_idx"], g[f"tm_query_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(t["train_idx"], g[f"tm_train_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(t["mask"], g[f"tm_mask_{p + 1}"], err_msg=f"RANSAC mask of pair {p}")
+        # what the reference handed to its refinement (fill_database.py:204-207)
+        np.testing.assert_array_equal(t["X_corr"][t["mask"]], g[f"refine_obj_{p}"])
+        np.testing.assert_array_equal(t["pix_L"][t["mask"]], g[f"refine_img_{p}"])
+        Rt, _ = so.refine_pose(t["X_corr"], t["pix_L"], cam.K, t["Rt_ransac"], t["mask"])
+        # same least-squares minimum, reached from another start
+        np.testing.assert_allclose(Rt, g["relative_Rts"][p], rtol=0, atol=1e-8)
+
+
+def test_consensus_check_equals_the_references(golden):
+    g = golden("ref_consensus_flow.npz")
+    cam = _Cam(g["P0"], g["P1"])
+    seed = int(g["seed0"])
+    outcomes = []
+    for i, (curr, cand, gate) in enumerate(g["cases"]):
+        kf_cand = (g[f"links_{cand}"], g[f"des_{cand}"])
+        kf_curr = (g[f"links_{curr}"], g[f"des_{curr}"])
+        calls = int(g[f"rng_calls_{i}"])
+        r = po.consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loop=int(gate),
+                                   p_success=0.99999, n_iter_max=1500, rng=np.random.default_rng(seed))
+        seed += calls
+        assert r["ok"] == bool(g[f"ok_{i}"]), f"case {i}"
+        outcomes.append((bool(r["ok"]), calls))
+        if calls == 0:
+            assert len(r["query_idx"]) < gate                 # stopped at the first gate, RANSAC never ran
+            continue
+        if not r["ok"]:
+            assert r["mask"].sum() < gate                     # stopped at the second gate
+            continue
+        np.testing.assert_array_equal(r["mask"], g[f"mask_{i}"])
+        np.testing.assert_array_equal(r["P3D"][r["mask"]], g[f"refine_obj_{i}"])
+        np.testing.assert_array_equal(r["ptsL"][r["mask"]], g[f"refine_img_{i}"])
+        # pixels kept for drawing (loop_closure.py:230-233): current and candidate left pixels of the inliers
+        np.testing.assert_array_equal(r["ptsL"][r["mask"]], g[f"inl_curr_{i}"])
+        cand_px = g[f"links_{cand}"][:, [0, 2]][r["query_idx"]].astype(np.float32)
+        np.testing.assert_array_equal(cand_px[r["mask"]], g[f"inl_cand_{i}"])
+        T = np.eye(4)
+        T[:3] = r["Rt"]
+        np.testing.assert_allclose(np.linalg.inv(T), g[f"delta_inv_{i}"], rtol=0, atol=1e-7)
+    # the fixture covers success, a stop at the first gate and a stop at the second
+    assert (True, 1) in outcomes and (False, 0) in outcomes and (False, 1) in outcomes
