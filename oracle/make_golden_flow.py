@@ -246,6 +246,23 @@ def main():
         out[f"tm_query_{k}"], out[f"tm_train_{k}"], out[f"tm_mask_{k}"] = a["mq"], a["mt"], a["mask"]
     for p in range(N_FRAMES - 1):
         out[f"refine_obj_{p}"], out[f"refine_img_{p}"] = log["refine_obj"][p], log["refine_img"][p]
+    # state of the TrackingDB that build() filled and serialised
+    db0 = TrackingDB()
+    db0.load(os.path.join(work, "tracks"))
+    db0._check_consistency()
+    fs = sorted(db0.frameId_to_trackIds_list)
+    out["db_track_ids"] = np.concatenate([np.asarray(db0.frameId_to_trackIds_list[f], np.int64) for f in fs])
+    out["db_track_ids_off"] = np.concatenate([[0], np.cumsum([len(db0.frameId_to_trackIds_list[f])
+                                                              for f in fs])]).astype(np.int64)
+    out["db_last_track"], out["db_last_frame"] = np.int64(db0.last_trackId), np.int64(db0.last_frameId)
+    keys = sorted(db0.linkId_to_link)
+    out["db_link_keys"] = np.asarray(keys, np.int64).reshape(-1, 2)
+    out["db_link_xyz"] = np.asarray([[db0.linkId_to_link[k].x_left, db0.linkId_to_link[k].x_right,
+                                      db0.linkId_to_link[k].y] for k in keys], np.float64).reshape(-1, 3)
+    tk = sorted(db0.trackId_to_frames)
+    out["db_track_keys"] = np.asarray(tk, np.int64)
+    out["db_track_len"] = np.asarray([len(db0.trackId_to_frames[t]) for t in tk], np.int64)
+    out["db_leftover_count"] = np.asarray([len(db0.leftover_links.get(f, [])) for f in fs], np.int64)
     np.savez_compressed(os.path.join(OUT, "ref_build_flow.npz"), **out)
     print("ref_build_flow.npz:", [len(a["links"]) for a in added], "stereo inliers;",
           [int(a["mask"].sum()) for a in added[1:]], "PnP inliers of", [len(a["mq"]) for a in added[1:]])

@@ -441,3 +441,13 @@ def test_front_end_against_the_references_own_frame_loop(golden):
         assert (got["mask"] != ref_mask).sum() <= 1, f"pair {p}: {(got['mask'] != ref_mask).sum()} points differ"
         if (got["mask"] == ref_mask).all():
             assert np.abs(got["Rt"] - g["relative_Rts"][p]).max() < 1e-6
+    if all((res.pair(p)["mask"] == g[f"tm_mask_{p + 1}"]).all() for p in range(F - 1)):
+        # then the hand-over fills the track database exactly as the reference's build() did
+        from oracle.tracking_db_oracle import TrackDBOracle
+        from slam_amd.backend.tracking import db_adapter
+        s = db_adapter.replay_into_db(TrackDBOracle(), res).summary()
+        for k in ("track_ids", "track_ids_off", "last_track", "last_frame", "link_keys", "link_xyz",
+                  "track_keys", "track_len", "leftover_count"):
+            np.testing.assert_array_equal(s[k], g["db_" + k], err_msg=k)
+    else:
+        pytest.skip("a borderline point fell on the other side of the threshold: no database comparison")
