@@ -201,71 +201,86 @@ def main():
         return real_rng(SEED0 + calls[0] - 1)
 
     # ------------------------------------------------- TrackingPipeline.build()
-    pipe = fd.TrackingPipeline.__new__(fd.TrackingPipeline)       # __init__ only builds cv2 objects
-    pipe.cam, pipe.img_seq, pipe.plot, pipe.relative_Rts, pipe.matcher_type = cam, Images(), False, None, "bf"
-    pipe.feature_extractor = Extractor()
-    pipe.stereo_matcher = DescriptorMatcher.__new__(DescriptorMatcher)
-    pipe.frame_matcher = DescriptorMatcher.__new__(DescriptorMatcher)
-    for m in (pipe.stereo_matcher, pipe.frame_matcher):
-        m.matcher_type, m.cross_check = "bf", False               # run_slam.py:34-35 defaults
-    pipe.triang = Triangulation(cam, 1.2, 4.0)                    # run_slam.py:31-32
-    pipe.pnp = PnP(cam, 4.0)
-
-    added = []
-    real_add = TrackingDB.add_frame
-
-    def add_frame(self, links, left_features, matches_to_previous_frame=None, inliers=None):
-        added.append({
-            "links": np.array([[l.x_left, l.x_right, l.y] for l in links], np.float64).reshape(-1, 3),
-            "des": np.asarray(left_features).copy(),
-            "mq": np.array([m.queryIdx for m in (matches_to_previous_frame or [])], np.int32),
-            "mt": np.array([m.trainIdx for m in (matches_to_previous_frame or [])], np.int32),
-            "mask": np.zeros(0, bool) if inliers is None else np.asarray(inliers, bool).copy()})
-        return real_add(self, links, left_features, matches_to_previous_frame, inliers)
-
-    TrackingDB.add_frame = add_frame
     cwd = os.getcwd()
     work = tempfile.mkdtemp(prefix="slamflow_")
-    os.chdir(work)
-    np.random.default_rng = seeded
-    try:
-        pipe.build(max_frame=N_FRAMES, out_path=os.path.join(work, "tracks"))
-    finally:
-        np.random.default_rng = real_rng
-        os.chdir(cwd)
-        TrackingDB.add_frame = real_add
-    n_rng_build = calls[0]
-    assert n_rng_build == N_FRAMES - 1 and len(added) == N_FRAMES
 
-    out = {"n_frames": N_FRAMES, "seed0": SEED0, "P0": np.array(mg.KITTI_P0), "P1": np.array(mg.KITTI_P1),
-           "relative_Rts": pipe.relative_Rts}
+    def run_build(cross_check: bool, name: str, prefix: str, out: dict):
+        pipe = fd.TrackingPipeline.__new__(fd.TrackingPipeline)       # __init__ only builds cv2 objects
+        pipe.cam, pipe.img_seq, pipe.plot, pipe.relative_Rts, pipe.matcher_type = cam, Images(), False, None, "bf"
+        pipe.feature_extractor = Extractor()
+        pipe.stereo_matcher = DescriptorMatcher.__new__(DescriptorMatcher)
+        pipe.frame_matcher = DescriptorMatcher.__new__(DescriptorMatcher)
+        for m in (pipe.stereo_matcher, pipe.frame_matcher):
+            m.matcher_type, m.cross_check = "bf", cross_check         # run_slam.py:34-35 (default False)
+        pipe.triang = Triangulation(cam, 1.2, 4.0)                    # run_slam.py:31-32
+        pipe.pnp = PnP(cam, 4.0)
+
+        added = []
+        real_add = TrackingDB.add_frame
+
+        def add_frame(self, links, left_features, matches_to_previous_frame=None, inliers=None):
+            ms = matches_to_previous_frame or []
+            added.append({
+                "links": np.array([[l.x_left, l.x_right, l.y] for l in links], np.float64).reshape(-1, 3),
+                "des": np.asarray(left_features).copy(),
+                "mq": np.array([m.queryIdx for m in ms], np.int32),
+                "mt": np.array([m.trainIdx for m in ms], np.int32),
+                "md": np.array([m.distance for m in ms], np.float32),
+                "mask": np.zeros(0, bool) if inliers is None else np.asarray(inliers, bool).copy()})
+            return real_add(self, links, left_features, matches_to_previous_frame, inliers)
+
+        TrackingDB.add_frame = add_frame
+        n_ref0, calls0 = len(log["refine_obj"]), calls[0]
+        os.chdir(work)
+        np.random.default_rng = seeded
+        try:
+            pipe.build(max_frame=N_FRAMES, out_path=os.path.join(work, name))
+        finally:
+            np.random.default_rng = real_rng
+            os.chdir(cwd)
+            TrackingDB.add_frame = real_add
+        assert calls[0] - calls0 == N_FRAMES - 1 and len(added) == N_FRAMES
+
+        out[prefix + "seed0"] = np.int64(SEED0 + calls0)
+        out[prefix + "relative_Rts"] = pipe.relative_Rts
+        for k in range(N_FRAMES):
+            a = added[k]
+            out[f"{prefix}links_{k}"], out[f"{prefix}inlier_des_{k}"] = a["links"], a["des"]
+            out[f"{prefix}tm_query_{k}"], out[f"{prefix}tm_train_{k}"] = a["mq"], a["mt"]
+            out[f"{prefix}tm_dist_{k}"], out[f"{prefix}tm_mask_{k}"] = a["md"], a["mask"]
+        for p in range(N_FRAMES - 1):
+            out[f"{prefix}refine_obj_{p}"] = log["refine_obj"][n_ref0 + p]
+            out[f"{prefix}refine_img_{p}"] = log["refine_img"][n_ref0 + p]
+        # state of the TrackingDB that build() filled and serialised
+        db0 = TrackingDB()
+        db0.load(os.path.join(work, name))
+        db0._check_consistency()
+        fs = sorted(db0.frameId_to_trackIds_list)
+        out[prefix + "db_track_ids"] = np.concatenate([np.asarray(db0.frameId_to_trackIds_list[f], np.int64) for f in fs])
+        out[prefix + "db_track_ids_off"] = np.concatenate(
+            [[0], np.cumsum([len(db0.frameId_to_trackIds_list[f]) for f in fs])]).astype(np.int64)
+        out[prefix + "db_last_track"] = np.int64(db0.last_trackId)
+        out[prefix + "db_last_frame"] = np.int64(db0.last_frameId)
+        keys = sorted(db0.linkId_to_link)
+        out[prefix + "db_link_keys"] = np.asarray(keys, np.int64).reshape(-1, 2)
+        out[prefix + "db_link_xyz"] = np.asarray([[db0.linkId_to_link[k].x_left, db0.linkId_to_link[k].x_right,
+                                                   db0.linkId_to_link[k].y] for k in keys], np.float64).reshape(-1, 3)
+        tk = sorted(db0.trackId_to_frames)
+        out[prefix + "db_track_keys"] = np.asarray(tk, np.int64)
+        out[prefix + "db_track_len"] = np.asarray([len(db0.trackId_to_frames[t]) for t in tk], np.int64)
+        out[prefix + "db_leftover_count"] = np.asarray([len(db0.leftover_links.get(f, [])) for f in fs], np.int64)
+        print(f"{name} (cross-check {cross_check}):", [len(a["links"]) for a in added], "stereo inliers;",
+              [int(a["mask"].sum()) for a in added[1:]], "PnP inliers of", [len(a["mq"]) for a in added[1:]],
+              "entries;", len(tk), "tracks")
+
+    out = {"n_frames": N_FRAMES, "P0": np.array(mg.KITTI_P0), "P1": np.array(mg.KITTI_P1)}
     for k, f in enumerate(frames):
         out[f"kp_left_{k}"], out[f"kp_right_{k}"], out[f"des_left_{k}"], out[f"des_right_{k}"] = f
-        a = added[k]
-        out[f"links_{k}"], out[f"inlier_des_{k}"] = a["links"], a["des"]
-        out[f"tm_query_{k}"], out[f"tm_train_{k}"], out[f"tm_mask_{k}"] = a["mq"], a["mt"], a["mask"]
-    for p in range(N_FRAMES - 1):
-        out[f"refine_obj_{p}"], out[f"refine_img_{p}"] = log["refine_obj"][p], log["refine_img"][p]
-    # state of the TrackingDB that build() filled and serialised
-    db0 = TrackingDB()
-    db0.load(os.path.join(work, "tracks"))
-    db0._check_consistency()
-    fs = sorted(db0.frameId_to_trackIds_list)
-    out["db_track_ids"] = np.concatenate([np.asarray(db0.frameId_to_trackIds_list[f], np.int64) for f in fs])
-    out["db_track_ids_off"] = np.concatenate([[0], np.cumsum([len(db0.frameId_to_trackIds_list[f])
-                                                              for f in fs])]).astype(np.int64)
-    out["db_last_track"], out["db_last_frame"] = np.int64(db0.last_trackId), np.int64(db0.last_frameId)
-    keys = sorted(db0.linkId_to_link)
-    out["db_link_keys"] = np.asarray(keys, np.int64).reshape(-1, 2)
-    out["db_link_xyz"] = np.asarray([[db0.linkId_to_link[k].x_left, db0.linkId_to_link[k].x_right,
-                                      db0.linkId_to_link[k].y] for k in keys], np.float64).reshape(-1, 3)
-    tk = sorted(db0.trackId_to_frames)
-    out["db_track_keys"] = np.asarray(tk, np.int64)
-    out["db_track_len"] = np.asarray([len(db0.trackId_to_frames[t]) for t in tk], np.int64)
-    out["db_leftover_count"] = np.asarray([len(db0.leftover_links.get(f, [])) for f in fs], np.int64)
+    run_build(False, "tracks", "", out)
+    n_rng_build = calls[0]
+    # both matchers cross-checked: fewer matches, and the densified hand-over of fill_database.py:209-223
+    run_build(True, "tracks_cc", "cc_", out)
     np.savez_compressed(os.path.join(OUT, "ref_build_flow.npz"), **out)
-    print("ref_build_flow.npz:", [len(a["links"]) for a in added], "stereo inliers;",
-          [int(a["mask"].sum()) for a in added[1:]], "PnP inliers of", [len(a["mq"]) for a in added[1:]])
 
     # ------------------------------------- LoopClosure.consensus_pnp_match()
     from slam.backend.tracking.database import TrackingDB as DB    # type: ignore
@@ -273,7 +288,7 @@ def main():
     db.load(os.path.join(work, "tracks"))
     loop = lc.LoopClosure(cam, None, None, None, None, frame_cross_check=False)
     cases = [(3, 0, 60), (4, 1, 40), (2, 0, 100000), (3, 0, 150)]                # (curr, cand, min_inliers_loop)
-    out = {"P0": np.array(mg.KITTI_P0), "P1": np.array(mg.KITTI_P1), "seed0": SEED0 + n_rng_build,
+    out = {"P0": np.array(mg.KITTI_P0), "P1": np.array(mg.KITTI_P1), "seed0": SEED0 + calls[0],
            "cases": np.array(cases, np.int64)}
     for frame in sorted({c for c, _, _ in cases} | {c for _, c, _ in cases}):
         links = db.all_frame_links(frame)

@@ -40,24 +40,51 @@ def frame_links(frame: dict, link_factory: Callable = Link) -> list:
             for a, b in zip(pl, pr)]
 
 
-def replay_into_db(db, result, link_factory: Callable = Link, n_frames: Optional[int] = None):
+def dense_matches(pair: dict, n_prev: int):
+    """The reference's densification (fill_database.py:209-223), used when the frame
+    matcher cross-checks: one entry per previous inlier row, in row order; rows without
+    a match hold DMatch(i, -1, 0, inf) and are no inliers.  Returns (MatchList, mask)."""
+    q = np.arange(n_prev, dtype=np.int32)
+    t = np.full(n_prev, -1, dtype=np.int32)
+    d = np.full(n_prev, np.inf, dtype=np.float32)
+    ok = np.zeros(n_prev, dtype=bool)
+    rows = np.asarray(pair["query_idx"], dtype=np.int64)
+    t[rows] = pair["train_idx"]
+    d[rows] = np.asarray(pair["dist"], dtype=np.float32)
+    ok[rows] = np.asarray(pair["mask"], dtype=bool)
+    return MatchList(q, t, d), ok
+
+
+def replay_into_db(db, result, link_factory: Callable = Link, n_frames: Optional[int] = None,
+                   frame_cross_check: Optional[bool] = None):
     """Feed a TrackingDB-like object (anything with the reference's
     `add_frame(links, left_features, matches_to_previous_left=None, inliers=None)`)
     with the frames of `result` (FrontendResult or SequenceResult), in order.
     Pass the reference's own Link class as `link_factory` when the DB will be
-    pickled for the reference's loader."""
+    pickled for the reference's loader.  `frame_cross_check` (default: what `result`
+    records, else False) selects the reference's two hand-over shapes: without it the
+    compact matches in sorted order, one per previous row; with it the densified list
+    (`dense_matches`), as add_frame requires one entry per previous row."""
     if n_frames is None:
         n_frames = result.n_frames if hasattr(result, "n_frames") else result.inputs.n_frames
+    if frame_cross_check is None:
+        frame_cross_check = bool(getattr(result, "frame_cross_check", False))
+    n_prev = 0
     for f in range(n_frames):
         fr = result.frame(f)
         links = frame_links(fr, link_factory)
         des = np.ascontiguousarray(fr["inlier_des_left"])
         if f == 0:
             db.add_frame(links, des, None)
-            continue
-        pr = result.pair(f - 1)
-        matches = MatchList(pr["query_idx"], pr["train_idx"], pr["dist"].astype(np.float32))
-        db.add_frame(links, des, matches, pr["mask"])
+        else:
+            pr = result.pair(f - 1)
+            if frame_cross_check:
+                matches, mask = dense_matches(pr, n_prev)
+            else:
+                matches = MatchList(pr["query_idx"], pr["train_idx"], pr["dist"].astype(np.float32))
+                mask = pr["mask"]
+            db.add_frame(links, des, matches, mask)
+        n_prev = len(des)
     return db
 
 
@@ -93,6 +120,7 @@ def save_records(result, path: str, n_frames: Optional[int] = None) -> str:
                   else np.zeros((0,), np.int32))
     out["Rt"] = (np.stack([np.asarray(p["Rt"], dtype=np.float64) for p in pairs]) if pairs
                  else np.zeros((0, 3, 4)))
+    out["frame_cross_check"] = np.bool_(getattr(result, "frame_cross_check", False))
     np.savez(path, **out)
     return path
 
@@ -104,6 +132,7 @@ class SavedRecords:
         with np.load(path, allow_pickle=False) as z:
             self._a = {k: z[k] for k in z.files}
         self.n_frames = int(self._a["n_frames"])
+        self.frame_cross_check = bool(self._a.get("frame_cross_check", False))
 
     def frame(self, f: int) -> dict:
         lo, hi = self._a["frame_off"][f], self._a["frame_off"][f + 1]

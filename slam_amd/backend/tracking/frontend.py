@@ -79,6 +79,7 @@ class FrontendInputs:
 class FrontendResult:
     def __init__(self, inputs: FrontendInputs, W: int, t: dict):
         self.inputs, self.W, self.t = inputs, W, t
+        self.frame_cross_check = False
         self._host = None
 
     def to_host(self) -> dict:
@@ -240,5 +241,6 @@ class TrackingFrontend:
         check(lib.slamhip_frontend_batch(C.byref(a), torch.cuda.current_stream().cuda_stream),
               "slamhip_frontend_batch")
         res = FrontendResult(inp, W, t)
+        res.frame_cross_check = self.frame_cross_check      # selects the hand-over shape (db_adapter)
         res._keepalive = (d_samples,)
         return res

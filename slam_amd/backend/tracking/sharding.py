@@ -141,6 +141,7 @@ class SequenceResult:
 
     def __init__(self, n_frames: int, desc_bytes: int, st_cnt, tm_cnt, fields: Dict[str, np.ndarray]):
         self.n_frames, self.desc_bytes = n_frames, desc_bytes
+        self.frame_cross_check = False        # set by run_sharded; selects the hand-over shape (db_adapter)
         self.st_cnt, self.tm_cnt, self.f = st_cnt, tm_cnt, fields
         self.st_off = np.concatenate([[0], np.cumsum(st_cnt)]).astype(np.int64)
         self.tm_off = np.concatenate([[0], np.cumsum(tm_cnt)]).astype(np.int64)
@@ -307,8 +308,11 @@ def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
     else:
         blob = torch.from_numpy(pack_records([], [], 0, 0, desc_bytes))
     if world == 1:
-        return merge_records([blob.cpu().numpy()], n_frames)
-    got = gather_records(blob, dst, group)
-    if got is None:
-        return None
-    return merge_records([g.cpu().numpy() for g in got], n_frames)
+        merged = merge_records([blob.cpu().numpy()], n_frames)
+    else:
+        got = gather_records(blob, dst, group)
+        if got is None:
+            return None
+        merged = merge_records([g.cpu().numpy() for g in got], n_frames)
+    merged.frame_cross_check = bool(getattr(frontend, "frame_cross_check", False))   # for the hand-over
+    return merged

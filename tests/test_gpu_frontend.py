@@ -407,47 +407,59 @@ def test_front_end_call_captures_into_a_hip_graph():
         np.testing.assert_array_equal(a[k], b[k], err_msg=f"pair {k}")
 
 
-def test_front_end_against_the_references_own_frame_loop(golden):
+@pytest.mark.parametrize("cross_check", [False, True])
+def test_front_end_against_the_references_own_frame_loop(golden, cross_check):
     """tests/golden/ref_build_flow.npz: what the reference's TrackingPipeline.build()
     handed to TrackingDB.add_frame and to its pose refinement when it ran, as it is, on
     these frames (its OpenCV leaves on the CPU restatement, its RANSAC sampler seeded;
-    oracle/make_golden_flow.py).  The batched HIP front-end on the same frames, with the
-    same sample sequence: identical links, inlier descriptors and temporal matches; the
-    same RANSAC inliers and relative poses up to the minimal solver's rounding."""
+    oracle/make_golden_flow.py), once with the default matchers and once with both
+    cross-checked (densified hand-over, fill_database.py:209-223).  The batched HIP
+    front-end on the same frames, with the same sample sequence: identical links, inlier
+    descriptors and temporal matches; the same RANSAC inliers and relative poses up to the
+    minimal solver's rounding; and then the same TrackingDB state through the adapter."""
+    from oracle.tracking_db_oracle import TrackDBOracle
     from slam_amd import CameraModel
+    from slam_amd.backend.tracking import db_adapter
     from slam_amd.backend.tracking.frontend import TrackingFrontend
     g = golden("ref_build_flow.npz")
-    F, seed0 = int(g["n_frames"]), int(g["seed0"])
+    px = "cc_" if cross_check else ""
+    F, seed0 = int(g["n_frames"]), int(g[px + "seed0"])
     cam = CameraModel.from_projections(g["P0"], g["P1"])
     frames = [(g[f"kp_left_{k}"], g[f"kp_right_{k}"], g[f"des_left_{k}"], g[f"des_right_{k}"]) for k in range(F)]
     n_iter = 2500
     samples = np.zeros((F - 1, n_iter, 4), np.int32)
     for p in range(F - 1):
         rng = np.random.default_rng(seed0 + p)          # the generator the reference's loop drew from
-        N = len(g[f"tm_query_{p + 1}"])
+        N = int((g[f"{px}tm_train_{p + 1}"] >= 0).sum())
         for i in range(200):                            # far more than the loop consumed
             samples[p, i] = rng.choice(N, 4, replace=False)
-    res = TrackingFrontend(cam, n_iter_max=n_iter).run(frames, samples=samples)
+    fe = TrackingFrontend(cam, n_iter_max=n_iter, stereo_cross_check=cross_check, frame_cross_check=cross_check)
+    res = fe.run(frames, samples=samples)
     for k in range(F):
         got = res.frame(k)
-        np.testing.assert_array_equal(got["links"], g[f"links_{k}"], err_msg=f"links of frame {k}")
-        np.testing.assert_array_equal(got["inlier_des_left"], g[f"inlier_des_{k}"])
+        np.testing.assert_array_equal(got["links"], g[f"{px}links_{k}"], err_msg=f"links of frame {k}")
+        np.testing.assert_array_equal(got["inlier_des_left"], g[f"{px}inlier_des_{k}"])
+    masks_equal = True
     for p in range(F - 1):
         got = res.pair(p)
-        np.testing.assert_array_equal(got["query_idx"], g[f"tm_query_{p + 1}"], err_msg=f"pair {p}")
-        np.testing.assert_array_equal(got["train_idx"], g[f"tm_train_{p + 1}"])
-        ref_mask = g[f"tm_mask_{p + 1}"]
+        if cross_check:
+            m, mask = db_adapter.dense_matches(got, len(g[f"{px}links_{p}"]))
+            q, tr = m.query_idx, m.train_idx
+        else:
+            q, tr, mask = got["query_idx"], got["train_idx"], got["mask"]
+        np.testing.assert_array_equal(q, g[f"{px}tm_query_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(tr, g[f"{px}tm_train_{p + 1}"])
+        ref_mask = g[f"{px}tm_mask_{p + 1}"]
         assert got["iterations"] < 200
-        assert (got["mask"] != ref_mask).sum() <= 1, f"pair {p}: {(got['mask'] != ref_mask).sum()} points differ"
-        if (got["mask"] == ref_mask).all():
-            assert np.abs(got["Rt"] - g["relative_Rts"][p]).max() < 1e-6
-    if all((res.pair(p)["mask"] == g[f"tm_mask_{p + 1}"]).all() for p in range(F - 1)):
-        # then the hand-over fills the track database exactly as the reference's build() did
-        from oracle.tracking_db_oracle import TrackDBOracle
-        from slam_amd.backend.tracking import db_adapter
-        s = db_adapter.replay_into_db(TrackDBOracle(), res).summary()
-        for k in ("track_ids", "track_ids_off", "last_track", "last_frame", "link_keys", "link_xyz",
-                  "track_keys", "track_len", "leftover_count"):
-            np.testing.assert_array_equal(s[k], g["db_" + k], err_msg=k)
-    else:
+        assert (mask != ref_mask).sum() <= 1, f"pair {p}: {(mask != ref_mask).sum()} points differ"
+        if (mask == ref_mask).all():
+            assert np.abs(got["Rt"] - g[px + "relative_Rts"][p]).max() < 1e-6
+        else:
+            masks_equal = False
+    if not masks_equal:
         pytest.skip("a borderline point fell on the other side of the threshold: no database comparison")
+    # then the hand-over fills the track database exactly as the reference's build() did
+    s = db_adapter.replay_into_db(TrackDBOracle(), res).summary()
+    for k in ("track_ids", "track_ids_off", "last_track", "last_frame", "link_keys", "link_xyz",
+              "track_keys", "track_len", "leftover_count"):
+        np.testing.assert_array_equal(s[k], g[px + "db_" + k], err_msg=k)

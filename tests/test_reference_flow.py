@@ -28,41 +28,53 @@ class _Cam:
         self.P_left, self.P_right = self.K @ self.M_left, self.K @ self.M_right
 
 
-def test_frame_loop_equals_the_references_build(golden):
+@pytest.mark.parametrize("cross_check", [False, True])
+def test_frame_loop_equals_the_references_build(golden, cross_check):
+    """cross_check=True: both matchers cross-checked (fewer matches) and the densified
+    hand-over of fill_database.py:209-223 (one entry per previous row, in row order,
+    DMatch(i, -1, 0, inf) where nothing matched)."""
+    from oracle.tracking_db_oracle import TrackDBOracle
+    from slam_amd.backend.tracking import db_adapter
     g = golden("ref_build_flow.npz")
+    px = "cc_" if cross_check else ""
     cam = _Cam(g["P0"], g["P1"])
-    F, seed0 = int(g["n_frames"]), int(g["seed0"])
+    F, seed0 = int(g["n_frames"]), int(g[px + "seed0"])
     frames = [(g[f"kp_left_{k}"], g[f"kp_right_{k}"], g[f"des_left_{k}"], g[f"des_right_{k}"]) for k in range(F)]
-    stereo = [po.stereo_stage(cam, f, pixel_thresh=4.0, disparity_min=1.2) for f in frames]
+    stereo = [po.stereo_stage(cam, f, pixel_thresh=4.0, disparity_min=1.2, cross_check=cross_check) for f in frames]
     for k, s in enumerate(stereo):
         # Link(x_left, x_right, (y_left + y_right) / 2) in match order (database.py:268-277)
         links = np.column_stack([s["pix_left"][:, 0].astype(np.float64), s["pix_right"][:, 0].astype(np.float64),
                                  (s["pix_left"][:, 1].astype(np.float64) + s["pix_right"][:, 1].astype(np.float64)) / 2])
-        np.testing.assert_array_equal(links, g[f"links_{k}"], err_msg=f"links of frame {k}")
-        np.testing.assert_array_equal(s["inlier_des_left"], g[f"inlier_des_{k}"], err_msg=f"descriptors of frame {k}")
-    assert len(g["tm_query_0"]) == 0 and len(g["tm_mask_0"]) == 0          # frame 0 has no previous frame
+        np.testing.assert_array_equal(links, g[f"{px}links_{k}"], err_msg=f"links of frame {k}")
+        np.testing.assert_array_equal(s["inlier_des_left"], g[f"{px}inlier_des_{k}"], err_msg=f"descriptors of frame {k}")
+    assert len(g[px + "tm_query_0"]) == 0 and len(g[px + "tm_mask_0"]) == 0      # frame 0 has no previous frame
     pairs = []
     for p in range(F - 1):
-        t = po.temporal_stage(cam, stereo[p], stereo[p + 1], pixel_thresh=4.0,
+        t = po.temporal_stage(cam, stereo[p], stereo[p + 1], pixel_thresh=4.0, cross_check=cross_check,
                               rng=np.random.default_rng(seed0 + p))
-        np.testing.assert_array_equal(t["query_idx"], g[f"tm_query_{p + 1}"], err_msg=f"pair {p}")
-        np.testing.assert_array_equal(t["train_idx"], g[f"tm_train_{p + 1}"], err_msg=f"pair {p}")
-        np.testing.assert_array_equal(t["mask"], g[f"tm_mask_{p + 1}"], err_msg=f"RANSAC mask of pair {p}")
+        if cross_check:
+            assert len(t["query_idx"]) < len(stereo[p]["left_idx"])           # the cross-check dropped some
+            m, mask = db_adapter.dense_matches(t, len(stereo[p]["left_idx"]))
+            q, tr, d = m.query_idx, m.train_idx, m.distance
+        else:
+            q, tr, d, mask = t["query_idx"], t["train_idx"], t["dist"].astype(np.float32), t["mask"]
+        np.testing.assert_array_equal(q, g[f"{px}tm_query_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(tr, g[f"{px}tm_train_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(d, g[f"{px}tm_dist_{p + 1}"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(mask, g[f"{px}tm_mask_{p + 1}"], err_msg=f"RANSAC mask of pair {p}")
         # what the reference handed to its refinement (fill_database.py:204-207)
-        np.testing.assert_array_equal(t["X_corr"][t["mask"]], g[f"refine_obj_{p}"])
-        np.testing.assert_array_equal(t["pix_L"][t["mask"]], g[f"refine_img_{p}"])
+        np.testing.assert_array_equal(t["X_corr"][t["mask"]], g[f"{px}refine_obj_{p}"])
+        np.testing.assert_array_equal(t["pix_L"][t["mask"]], g[f"{px}refine_img_{p}"])
         Rt, _ = so.refine_pose(t["X_corr"], t["pix_L"], cam.K, t["Rt_ransac"], t["mask"])
         # same least-squares minimum, reached from another start
-        np.testing.assert_allclose(Rt, g["relative_Rts"][p], rtol=0, atol=1e-8)
+        np.testing.assert_allclose(Rt, g[px + "relative_Rts"][p], rtol=0, atol=1e-8)
         pairs.append(dict(t, Rt=Rt))
 
     # the TrackingDB the reference's build() filled == these records handed over by the
     # adapter to the restated add_frame (track ids per feature, every link, track lengths)
-    from oracle.tracking_db_oracle import TrackDBOracle
-    from slam_amd.backend.tracking import db_adapter
-
     class Records:
         n_frames = F
+        frame_cross_check = cross_check
 
         def frame(self, f):
             return stereo[f]
@@ -72,7 +84,7 @@ def test_frame_loop_equals_the_references_build(golden):
     s = db_adapter.replay_into_db(TrackDBOracle(), Records()).summary()
     for k in ("track_ids", "track_ids_off", "last_track", "last_frame", "link_keys", "link_xyz", "track_keys",
               "track_len", "leftover_count"):
-        np.testing.assert_array_equal(s[k], g["db_" + k], err_msg=k)
+        np.testing.assert_array_equal(s[k], g[px + "db_" + k], err_msg=k)
     assert (s["track_len"] >= 2).all() and len(s["track_keys"]) > 100
 
 
