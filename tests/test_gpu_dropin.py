@@ -1,0 +1,73 @@
+"""The reference's frame loop written against the drop-in classes.
+
+The integration is a change of three imports at the reference's call sites
+(backend/tracking/fill_database.py:7-10): DescriptorMatcher, Triangulation and PnP come
+from slam_amd instead.  This test is that frame loop, statement for statement
+(fill_database.py:102-240, features given, default matchers), on the frames of
+tests/golden/ref_build_flow.npz, and compares what it would hand to
+TrackingDB.add_frame with what the reference's own build() handed over when it ran on
+the same frames (oracle/make_golden_flow.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _create_links(features, kp_left, kp_right, matches):
+    """TrackingDB.create_links(..., inliers=None, keep_match_order=True) (database.py:256-285)."""
+    links = [(kp_left[m.queryIdx].pt[0], kp_right[m.trainIdx].pt[0],
+              (kp_left[m.queryIdx].pt[1] + kp_right[m.trainIdx].pt[1]) / 2) for m in matches]
+    return features[[m.queryIdx for m in matches]], np.array(links, np.float64).reshape(-1, 3)
+
+
+def test_reference_frame_loop_on_the_drop_in_classes(golden):
+    from slam_amd import CameraModel, DescriptorMatcher, KeyPoint, PnP, Triangulation, SOLVEPNP_ITERATIVE
+    g = golden("ref_build_flow.npz")
+    F, seed0 = int(g["n_frames"]), int(g["seed0"])
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    stereo_matcher = DescriptorMatcher(cross_check=False, matcher_type="bf")        # :67-78
+    frame_matcher = DescriptorMatcher(cross_check=False, matcher_type="bf")
+    triang = Triangulation(cam, 1.2, 4.0)                                           # :81
+    pnp = PnP(cam, 4.0)                                                             # :82
+
+    def detect(k):
+        kl = [KeyPoint(x, y, 1) for x, y in g[f"kp_left_{k}"]]
+        kr = [KeyPoint(x, y, 1) for x, y in g[f"kp_right_{k}"]]
+        return kl, g[f"des_left_{k}"], kr, g[f"des_right_{k}"]
+
+    kp_L_prev, des_L_prev, kp_R_prev, des_R_prev = detect(0)
+    matches_LR_prev = stereo_matcher.match(des_L_prev, des_R_prev)                  # :114
+    inliers_LR_prev = triang.create_inlier_outlier_matches(matches_LR_prev, kp_L_prev, kp_R_prev)[0]   # :116-118
+    X_prev = triang.triangulate_opencv(kp_L_prev, kp_R_prev, inliers_LR_prev)       # :121
+    inlier_des_L_prev, links_prev = _create_links(des_L_prev, kp_L_prev, kp_R_prev, inliers_LR_prev)  # :124-131
+    np.testing.assert_array_equal(links_prev, g["links_0"])
+    np.testing.assert_array_equal(inlier_des_L_prev, g["inlier_des_0"])
+    assert X_prev.dtype == np.float32 and X_prev.shape == (len(links_prev), 3)
+
+    for idx in range(1, F):                                                         # :140
+        kp_L, des_L, kp_R, des_R = detect(idx)
+        matches_LR = stereo_matcher.match(des_L, des_R)                             # :155
+        inliers_LR = triang.create_inlier_outlier_matches(matches_LR, kp_L, kp_R)[0]   # :158-160
+        X_curr = triang.triangulate_opencv(kp_L, kp_R, inliers_LR)                  # :163
+        inlier_des_L, links_curr = _create_links(des_L, kp_L, kp_R, inliers_LR)     # :166-169
+        matches01 = frame_matcher.match(inlier_des_L_prev, inlier_des_L)            # :185
+        X_corr = X_prev[[m.queryIdx for m in matches01]]                            # :189-190
+        inlier_idx_L = [m.queryIdx for m in inliers_LR]                             # :193
+        pix_L, pix_R = pnp.create_L_R_pixels(matches01, inliers_LR, inlier_idx_L, kp_L, kp_R, pair_0_or_1=1)  # :195-197
+        mask = pnp.ransac_pnp_pair1(X_corr, pix_L, pix_R,                           # :200-202
+                                    rng=np.random.default_rng(seed0 + idx - 1))
+        Rt = pnp.solve_pnp(X_corr[mask], pix_L[mask], SOLVEPNP_ITERATIVE)            # :204-207
+
+        np.testing.assert_array_equal(links_curr, g[f"links_{idx}"], err_msg=f"frame {idx}")
+        np.testing.assert_array_equal(inlier_des_L, g[f"inlier_des_{idx}"])
+        assert len(matches01) == len(inlier_des_L_prev)                             # database.py:332
+        np.testing.assert_array_equal([m.queryIdx for m in matches01], g[f"tm_query_{idx}"])
+        np.testing.assert_array_equal([m.trainIdx for m in matches01], g[f"tm_train_{idx}"])
+        np.testing.assert_array_equal(np.array([m.distance for m in matches01], np.float32), g[f"tm_dist_{idx}"])
+        ref_mask = g[f"tm_mask_{idx}"]
+        assert mask.dtype == bool and (mask != ref_mask).sum() <= 1
+        if (mask == ref_mask).all():
+            np.testing.assert_array_equal(X_corr[mask], g[f"refine_obj_{idx - 1}"].astype(np.float32))
+            np.testing.assert_array_equal(pix_L[mask], g[f"refine_img_{idx - 1}"])
+            assert np.abs(Rt - g["relative_Rts"][idx - 1]).max() < 1e-6
+        X_prev, inlier_des_L_prev = X_curr, inlier_des_L                            # :234-236
