@@ -323,6 +323,14 @@ int slamhip_frontend_batch(const slamhip_frontend_args *args, void *stream);
 /* [d_tbase[p], +d_tcnt[p]) of the per-keyframe arrays; its per-match        */
 /* outputs are at d_obase[p] (the caller lays pairs out back to back:        */
 /* n_out_total = sum of d_qcnt).                                             */
+/*                                                                           */
+/* cross_check != 0: the matcher of :192 was built with crossCheck           */
+/* (LoopClosure's frame_cross_check): a candidate row keeps, among the rows  */
+/* of the current keyframe that chose it, the closest (lowest row on ties);  */
+/* rows nobody chose have no match, so a pair yields d_info[8p+5] <= d_qcnt  */
+/* matches.  The swapped matcher needs one scratch row per (pair, current-   */
+/* keyframe row): d_tobase[p] = sum of d_tcnt over the pairs before p,       */
+/* n_tout_total = sum of d_tcnt.                                             */
 /* ------------------------------------------------------------------------- */
 typedef struct slamhip_verify_args {
   int32_t n_rows_total;                  /* rows of the per-keyframe arrays */
@@ -333,7 +341,7 @@ typedef struct slamhip_verify_args {
   const int32_t *d_qbase, *d_qcnt, *d_tbase, *d_tcnt, *d_obase; /* n_pairs each (device) */
   double K[9], M_right[12], P_left[12], P_right[12];   /* host values */
   double ransac_thresh, p_success;
-  int32_t n_iter_max, min_points, refine_iters, reserved;
+  int32_t n_iter_max, min_points, refine_iters, cross_check;
   uint64_t seed;
   /* outputs */
   float *d_xyz;                          /* n_rows_total*3: keyframe points */
@@ -343,6 +351,9 @@ typedef struct slamhip_verify_args {
   int32_t *d_info;                       /* n_pairs*8, as d_ransac_info above */
   void *d_workspace;
   size_t workspace_bytes;
+  /* cross_check only */
+  const int32_t *d_tobase;               /* n_pairs (device) */
+  int32_t n_tout_total, reserved;
 } slamhip_verify_args;
 
 size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *args);

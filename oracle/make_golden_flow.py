@@ -287,17 +287,18 @@ def main():
     db = DB()
     db.load(os.path.join(work, "tracks"))
     loop = lc.LoopClosure(cam, None, None, None, None, frame_cross_check=False)
-    cases = [(3, 0, 60), (4, 1, 40), (2, 0, 100000), (3, 0, 150)]                # (curr, cand, min_inliers_loop)
+    # (curr, cand, min_inliers_loop, frame_cross_check)
+    cases = [(3, 0, 60, 0), (4, 1, 40, 0), (2, 0, 100000, 0), (3, 0, 150, 0), (3, 1, 60, 1), (4, 0, 199, 1)]
     out = {"P0": np.array(mg.KITTI_P0), "P1": np.array(mg.KITTI_P1), "seed0": SEED0 + calls[0],
            "cases": np.array(cases, np.int64)}
-    for frame in sorted({c for c, _, _ in cases} | {c for _, c, _ in cases}):
+    for frame in sorted({c[0] for c in cases} | {c[1] for c in cases}):
         links = db.all_frame_links(frame)
         out[f"links_{frame}"] = np.array([[l.x_left, l.x_right, l.y] for l in links], np.float64)
         out[f"des_{frame}"] = np.asarray(db.features(frame))
     np.random.default_rng = seeded
     try:
-        for i, (curr, cand, gate) in enumerate(cases):
-            loop.min_inliers_loop = gate
+        for i, (curr, cand, gate, cc) in enumerate(cases):
+            loop.min_inliers_loop, loop.frame_cross_check = gate, bool(cc)
             n_ref = len(log["refine_obj"])
             before = calls[0]
             ok, delta_inv, mask, ids, px = loop.consensus_pnp_match(curr, cand, db)
@@ -310,7 +311,7 @@ def main():
             out[f"refine_img_{i}"] = log["refine_img"][-1] if refined else np.zeros((0, 2), np.float32)
             out[f"inl_curr_{i}"] = px.get("inl_curr", np.zeros((0, 2), np.float32))
             out[f"inl_cand_{i}"] = px.get("inl_cand", np.zeros((0, 2), np.float32))
-            print(f"consensus case {i}: curr {curr} cand {cand} gate {gate}: ok={ok}",
+            print(f"consensus case {i}: curr {curr} cand {cand} gate {gate} cross-check {cc}: ok={ok}",
                   "" if mask is None else f"{int(mask.sum())}/{len(mask)} inliers")
     finally:
         np.random.default_rng = real_rng

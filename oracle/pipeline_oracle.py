@@ -113,15 +113,17 @@ def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=T
 
 
 def consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loop=60,
-                        p_success=0.99999, n_iter_max=1500, rng=None, knn2=None, refine=True):
+                        p_success=0.99999, n_iter_max=1500, rng=None, knn2=None, refine=True,
+                        cross_check=False):
     """LoopClosure.consensus_pnp_match (backend/optimizers/loop_closure.py:167-235)
-    up to the refined pose.  kf = (links (n,3) [x_left, x_right, y], des_left)."""
+    up to the refined pose.  kf = (links (n,3) [x_left, x_right, y], des_left);
+    cross_check = LoopClosure's frame_cross_check (the matcher of :192)."""
     links_i, des_i = kf_cand
     links_n, des_n = kf_curr
     kpL_i, kpR_i = links_i[:, [0, 2]], links_i[:, [1, 2]]              # frame_data, :152-164
     kpL_n, kpR_n = links_n[:, [0, 2]], links_n[:, [1, 2]]
     obj = so.triangulate_cv(cam.P_left, cam.P_right, kpL_i, kpR_i, out_fp64=True)   # :179-180
-    qi, ti, di = _bf_match(des_i, des_n, knn2)                          # :192-195
+    qi, ti, di = _bf_match(des_i, des_n, knn2, cross_check)             # :192-195
     out = {"query_idx": qi, "train_idx": ti, "dist": di, "obj": obj, "ok": False, "Rt": None,
            "mask": np.zeros(len(qi), bool)}
     if len(qi) < min_inliers_loop:                                      # :206-207

@@ -101,11 +101,12 @@ class VerifyArgs(C.Structure):
         ("K", C.c_double * 9), ("M_right", C.c_double * 12),
         ("P_left", C.c_double * 12), ("P_right", C.c_double * 12),
         ("ransac_thresh", _d), ("p_success", _d),
-        ("n_iter_max", _i32), ("min_points", _i32), ("refine_iters", _i32), ("reserved", _i32),
+        ("n_iter_max", _i32), ("min_points", _i32), ("refine_iters", _i32), ("cross_check", _i32),
         ("seed", _u64),
         ("d_xyz", _vp), ("d_tm_query", _vp), ("d_tm_train", _vp), ("d_tm_dist", _vp),
         ("d_tm_mask", _vp), ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_info", _vp),
         ("d_workspace", _vp), ("workspace_bytes", _sz),
+        ("d_tobase", _vp), ("n_tout_total", _i32), ("reserved", _i32),
     ]
 
 

@@ -49,7 +49,10 @@ class VerifyResult(dict):
         return dict.__contains__(self, key) or key in self._LAZY
 
     def pair_matches(self, p: int) -> dict:
-        lo, hi = int(self["out_off"][p]), int(self["out_off"][p + 1])
+        """Matches of pair p: rows out_off[p] .. out_off[p] + n_matches[p] (all of the pair's
+        rows without cross-check)."""
+        lo = int(self["out_off"][p])
+        hi = lo + int(self["n_matches"][p])
         out = {}
         for key, (name, cast) in self._LAZY.items():
             if key == "xyz":
@@ -63,7 +66,7 @@ class VerifyResult(dict):
         per-match arrays of just those pairs, concatenated in that order}."""
         idx = np.flatnonzero(self["ok"])
         start = self["out_off"][idx].astype(np.int64)
-        count = (self["out_off"][idx + 1] - self["out_off"][idx]).astype(np.int64)
+        count = self["n_matches"][idx].astype(np.int64)
         off = np.concatenate([[0], np.cumsum(count)]).astype(np.int64)
         out = {"pairs": idx, "off": off}
         dev = self._dev["tm_query"].device
@@ -86,8 +89,11 @@ class PairVerifier:
 
     def __init__(self, cam, pixel_thresh: float = 1.5, min_inliers_loop: int = 60,
                  p_success: float = 0.99999, n_iter_max: int = 1500, refine_iters: int = 30,
-                 seed: int = 0):
+                 seed: int = 0, frame_cross_check: bool = False):
         self.cam = cam
+        # crossCheck of the matcher consensus_pnp_match builds (loop_closure.py:192: LoopClosure's
+        # frame_cross_check, run_slam.py:35; default False)
+        self.frame_cross_check = bool(frame_cross_check)
         self.pixel_thresh, self.min_inliers = float(pixel_thresh), int(min_inliers_loop)
         self.p_success, self.n_iter_max = float(p_success), int(n_iter_max)
         self.refine_iters, self.seed = int(refine_iters), int(seed)
@@ -134,6 +140,10 @@ class PairVerifier:
         i32 = lambda a: kernels.to_device(np.ascontiguousarray(a, dtype=np.int32), torch.int32)
         d_qbase, d_qcnt = i32(kf["off"][cand]), i32(qcnt)
         d_tbase, d_tcnt, d_obase = i32(kf["off"][curr]), i32(tcnt), i32(obase[:-1])
+        tobase = np.concatenate([[0], np.cumsum(tcnt)])
+        if int(tobase[-1]) >= 2 ** 31:
+            raise ValueError("too many rows for 32-bit offsets; split the pair list")
+        d_tobase = i32(tobase[:-1])
         out = {
             "xyz": torch.empty(max(N, 1) * 3, dtype=torch.float32, device=dev),
             "tm_query": torch.empty(max(O, 1), dtype=torch.int32, device=dev),
@@ -158,6 +168,8 @@ class PairVerifier:
         a.ransac_thresh, a.p_success = self.pixel_thresh, self.p_success
         a.n_iter_max, a.min_points, a.refine_iters = self.n_iter_max, self.min_inliers, self.refine_iters
         a.seed = self.seed
+        a.cross_check = int(self.frame_cross_check)
+        a.d_tobase, a.n_tout_total = d_tobase.data_ptr(), int(tobase[-1])
         a.d_xyz = out["xyz"].data_ptr()
         a.d_tm_query, a.d_tm_train = out["tm_query"].data_ptr(), out["tm_train"].data_ptr()
         a.d_tm_dist, a.d_tm_mask = out["tm_dist"].data_ptr(), out["tm_mask"].data_ptr()

@@ -131,13 +131,14 @@ __global__ __launch_bounds__(kBlock) void stereo_points_kernel(
 // with one atomic minimum on a key per query row, so a query keeps the closest
 // of the train rows that chose it, lowest train index on ties -- the fold of
 // cv2's batchDistance -- in O(rows) instead of a scan per query.
-// Pair p: train rows [tbase[p], +tcnt[p]) hold their choice in r_idx2 / r_dist2
-// (row-indexed like the rows themselves); query rows start at qbase[p].
+// Pair p: its tcnt[p] train rows hold their choice in r_idx2 / r_dist2 at rows
+// rbase[p] + t (the rows themselves in the front-end; a scratch row per (pair, row)
+// where pairs share rows); the bids of its query rows are at qbase[p] + query.
 // --------------------------------------------------------------------------
 constexpr uint32_t kBidShift = 21, kBidIdxMask = (1u << kBidShift) - 1u, kNoBid = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(kBlock) void cross_bid_kernel(
-    const int32_t *__restrict__ tbase, const int32_t *__restrict__ tcnt_or_null,
+    const int32_t *__restrict__ tbase /* = rbase */, const int32_t *__restrict__ tcnt_or_null,
     const int32_t *__restrict__ qbase, const int32_t *__restrict__ r_idx2,
     const int32_t *__restrict__ r_dist2, uint32_t *__restrict__ bid) {
   const int p = blockIdx.y;
@@ -846,6 +847,19 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
 // ---------------------------------------------------------------------------
 // Pair verification (loop-closure candidates).
 // ---------------------------------------------------------------------------
+// workspace of the matcher calls of a chunk of pairs (forward, and swapped when cross-checking)
+static size_t verify_knn_bytes(const slamhip_verify_args *a, int chunk) {
+  size_t k = slamhip_internal::knn2_workspace_bytes(a->n_rows_total, a->n_rows_total, chunk, a->max_q,
+                                                    a->max_t, a->desc_bytes, (long long)a->n_out_total, true);
+  if (a->cross_check) {
+    const size_t k2 = slamhip_internal::knn2_workspace_bytes(
+        a->n_rows_total, a->n_rows_total, chunk, a->max_t, a->max_q, a->desc_bytes,
+        (long long)(a->n_tout_total > 0 ? a->n_tout_total : 0), true);
+    if (k2 > k) k = k2;
+  }
+  return k;
+}
+
 size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
   if (!a || a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0 || a->desc_bytes < 1 ||
       a->desc_bytes > SLAMHIP_MAX_DESC_BYTES)
@@ -860,10 +874,12 @@ size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
   take(O * 4);                // order
   take(O * 12); take(O * 8); take(O * 8);  // cx, cpl, cpr
   take((size_t)(a->n_pairs > 0 ? a->n_pairs : 1) * 4);  // counts
-  take(slamhip_internal::knn2_workspace_bytes(a->n_rows_total, a->n_rows_total, chunk, a->max_q,
-                                              a->max_t, a->desc_bytes, (long long)a->n_out_total,
-                                              true));
+  take(verify_knn_bytes(a, chunk));
   take(ransac_workspace_bytes(chunk, a->n_iter_max));
+  if (a->cross_check) {
+    const size_t TO = (size_t)(a->n_tout_total > 0 ? a->n_tout_total : 0);
+    take(TO * 8); take(TO * 8); take(O * 4);   // swapped matcher's result, bids
+  }
   return o + 256;
 }
 
@@ -891,11 +907,18 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
   float *cx = (float *)take(O * 12), *cpl = (float *)take(O * 8), *cpr = (float *)take(O * 8);
   int32_t *tcount = (int32_t *)take((size_t)(a->n_pairs > 0 ? a->n_pairs : 1) * 4);
   const int chunk_max = a->n_pairs < 32768 ? (a->n_pairs > 0 ? a->n_pairs : 1) : 32768;
-  const size_t knn_bytes = slamhip_internal::knn2_workspace_bytes(
-      a->n_rows_total, a->n_rows_total, chunk_max, a->max_q, a->max_t, a->desc_bytes,
-      (long long)a->n_out_total, true);
+  const size_t knn_bytes = verify_knn_bytes(a, chunk_max);
   void *knn_ws = (void *)take(knn_bytes);
   void *ransac_ws = (void *)take(ransac_workspace_bytes(chunk_max, a->n_iter_max));
+  int32_t *ridx2 = nullptr, *rdist2 = nullptr;
+  uint32_t *bid = nullptr;
+  if (a->cross_check) {
+    if (a->n_tout_total < 0 || (a->n_pairs > 0 && !a->d_tobase)) return SLAMHIP_EINVAL;
+    const size_t TO = (size_t)a->n_tout_total;
+    ridx2 = (int32_t *)take(TO * 8);
+    rdist2 = (int32_t *)take(TO * 8);
+    bid = (uint32_t *)take(O * 4);
+  }
 
   // per keyframe: points of all stored features (loop_closure.py:179-180,237-249: fp64
   // triangulation, later cast to float32 at :209) and packed descriptors
@@ -926,11 +949,30 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
     const int np = a->n_pairs - c0 < chunk_max ? a->n_pairs - c0 : chunk_max;
     const int32_t *qb = a->d_qbase + c0, *qc = a->d_qcnt + c0, *tb = a->d_tbase + c0,
                   *tc = a->d_tcnt + c0, *ob = a->d_obase + c0;
-    rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
-                                a->n_rows_total, a->desc_bytes, W * 4, true, qb, qc, tb, tc, np,
-                                a->max_q, a->max_t, idx2, dist2, knn_ws, knn_bytes, st, ob,
-                                a->n_out_total, true);
-    if (rc) return rc;
+    if (!a->cross_check) {
+      rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
+                                  a->n_rows_total, a->desc_bytes, W * 4, true, qb, qc, tb, tc, np,
+                                  a->max_q, a->max_t, idx2, dist2, knn_ws, knn_bytes, st, ob,
+                                  a->n_out_total, true);
+      if (rc) return rc;
+    } else {
+      // the rows of the current keyframe choose among the candidate's, then bid for them
+      const int32_t *tob = a->d_tobase + c0;
+      if (c0 == 0 && hipMemsetAsync(bid, 0xFF, sizeof(uint32_t) * O, st) != hipSuccess)
+        return SLAMHIP_ELAUNCH;
+      if (a->max_t > 0 && a->n_tout_total > 0) {
+        rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
+                                    a->n_rows_total, a->desc_bytes, W * 4, true, tb, tc, qb, qc, np,
+                                    a->max_t, a->max_q, ridx2, rdist2, knn_ws, knn_bytes, st, tob,
+                                    a->n_tout_total, true);
+        if (rc) return rc;
+        hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_t, kBlock), np), dim3(kBlock), 0,
+                           st, tob, tc, ob, ridx2, rdist2, bid);
+      }
+      hipLaunchKernelGGL(cross_decode_kernel, dim3(slamhip_ceil_div(a->n_out_total, kBlock)), dim3(kBlock),
+                         0, st, bid, a->n_out_total, idx2, dist2);
+      SLAMHIP_CHECK_LAUNCH();
+    }
     rc = slamhip_internal::sort_by_distance(dist2, 2, ob, qc, np, a->max_q, order, st);
     if (rc) return rc;
     hipLaunchKernelGGL(temporal_gather_kernel<double>, dim3(slamhip_ceil_div(a->max_q, kBlock), np),

@@ -117,20 +117,60 @@ def test_verify_against_the_references_own_consensus_check(golden):
     cam = CameraModel.from_projections(g["P0"], g["P1"])
     ids = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("links_"))
     keyframes = [(g[f"links_{k}"], g[f"des_{k}"]) for k in ids]
-    for i, (curr, cand, gate) in enumerate(g["cases"]):
-        ver = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i).set_keyframes(keyframes)
+    for i, (curr, cand, gate, cc) in enumerate(g["cases"]):
+        ver = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i,
+                           frame_cross_check=bool(cc)).set_keyframes(keyframes)
         res = ver.verify(np.array([[ids.index(int(cand)), ids.index(int(curr))]], dtype=np.int64))
         assert bool(res["ok"][0]) == bool(g[f"ok_{i}"]), f"case {i}"
         if int(g[f"rng_calls_{i}"]) == 0:
             assert res["iterations"][0] == 0              # first gate: RANSAC never ran
         if not res["ok"][0]:
             continue
-        sl = slice(int(res["out_off"][0]), int(res["out_off"][1]))
+        mask = res.pair_matches(0)["mask"]
         ref_mask = g[f"mask_{i}"]
-        assert len(res["mask"][sl]) == len(ref_mask)      # one match per candidate feature
-        assert res["mask"][sl].sum() >= gate and ref_mask.sum() >= gate
-        assert (res["mask"][sl] & ref_mask).sum() > 0.5 * ref_mask.sum()
+        assert len(mask) == len(ref_mask)                 # the same matches (one per candidate feature unless cross-checked)
+        assert mask.sum() >= gate and ref_mask.sum() >= gate
+        assert (mask & ref_mask).sum() > 0.5 * ref_mask.sum()
         T = np.eye(4)
         T[:3] = res["Rt"][0]
         D = np.linalg.inv(T) - g[f"delta_inv_{i}"]
         assert np.abs(D[:3, :3]).max() < 5e-3 and np.abs(D[:3, 3]).max() < 0.15, D
+
+
+def test_verify_pairs_with_cross_checked_matcher():
+    """frame_cross_check=True (the matcher of loop_closure.py:192 built with crossCheck):
+    fewer matches per pair, the same ones as the CPU restatement, in the same order; the
+    decision agrees and the pose is the least-squares minimum on the device's own mask."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=70, n_features=700, seed=8, clutter=0.4)
+    kf_ids = [0, 2, 3, 60, 61]
+    keyframes = []
+    for k in kf_ids:
+        f = seq.frame(k)
+        st = po.stereo_stage(cam, (f.kp_left, f.kp_right, f.des_left, f.des_right))
+        pl, pr = st["pix_left"].astype(np.float64), st["pix_right"].astype(np.float64)
+        keyframes.append((np.column_stack([pl[:, 0], pr[:, 0], (pl[:, 1] + pr[:, 1]) / 2]), st["inlier_des_left"]))
+    keyframes[2] = (keyframes[2][0][:150], keyframes[2][1][:150])        # pairs of unequal size
+    pairs = np.array([(i, n) for n in range(len(kf_ids)) for i in range(n)], dtype=np.int64)
+    res = PairVerifier(cam, seed=5, frame_cross_check=True).set_keyframes(keyframes).verify(pairs)
+    plain = PairVerifier(cam, seed=5).set_keyframes(keyframes).verify(pairs)
+    n_ok = 0
+    for p, (i, n) in enumerate(pairs):
+        ref = po.consensus_pnp_match(cam, keyframes[i], keyframes[n], rng=np.random.default_rng(p), cross_check=True)
+        got = res.pair_matches(p)
+        assert res["n_matches"][p] == len(ref["query_idx"]) <= len(keyframes[i][0])
+        np.testing.assert_array_equal(got["query_idx"], ref["query_idx"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(got["train_idx"], ref["train_idx"])
+        np.testing.assert_array_equal(got["dist"], ref["dist"])
+        assert res["n_matches"][p] <= plain["n_matches"][p]
+        assert bool(res["ok"][p]) == bool(ref["ok"]), (p, res["n_inliers"][p], ref.get("best_count"))
+        if res["ok"][p]:
+            n_ok += 1
+            gold, _ = so.refine_pose(ref["P3D"], ref["ptsL"], cam.K, res["Rt_ransac"][p], got["mask"])
+            assert np.abs(res["Rt"][p] - gold).max() < 1e-7
+    assert (res["n_matches"] < plain["n_matches"]).any() and 2 <= n_ok < len(pairs)
+    vm = res.verified_matches()
+    assert vm["off"][-1] == res["n_matches"][res["ok"]].sum() == len(vm["mask"])

@@ -93,22 +93,26 @@ def test_consensus_check_equals_the_references(golden):
     cam = _Cam(g["P0"], g["P1"])
     seed = int(g["seed0"])
     outcomes = []
-    for i, (curr, cand, gate) in enumerate(g["cases"]):
+    for i, (curr, cand, gate, cc) in enumerate(g["cases"]):
         kf_cand = (g[f"links_{cand}"], g[f"des_{cand}"])
         kf_curr = (g[f"links_{curr}"], g[f"des_{curr}"])
         calls = int(g[f"rng_calls_{i}"])
         r = po.consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loop=int(gate),
-                                   p_success=0.99999, n_iter_max=1500, rng=np.random.default_rng(seed))
+                                   p_success=0.99999, n_iter_max=1500, rng=np.random.default_rng(seed),
+                                   cross_check=bool(cc))
         seed += calls
         assert r["ok"] == bool(g[f"ok_{i}"]), f"case {i}"
         outcomes.append((bool(r["ok"]), calls))
         if calls == 0:
             assert len(r["query_idx"]) < gate                 # stopped at the first gate, RANSAC never ran
+            if cc:                                            # ... which only the cross-check made happen
+                assert len(kf_cand[0]) >= gate
             continue
         if not r["ok"]:
             assert r["mask"].sum() < gate                     # stopped at the second gate
             continue
         np.testing.assert_array_equal(r["mask"], g[f"mask_{i}"])
+        assert (len(r["mask"]) < len(kf_cand[0])) == bool(cc)  # cross-checked: fewer matches than candidate rows
         np.testing.assert_array_equal(r["P3D"][r["mask"]], g[f"refine_obj_{i}"])
         np.testing.assert_array_equal(r["ptsL"][r["mask"]], g[f"refine_img_{i}"])
         # pixels kept for drawing (loop_closure.py:230-233): current and candidate left pixels of the inliers
@@ -120,3 +124,4 @@ def test_consensus_check_equals_the_references(golden):
         np.testing.assert_allclose(np.linalg.inv(T), g[f"delta_inv_{i}"], rtol=0, atol=1e-7)
     # the fixture covers success, a stop at the first gate and a stop at the second
     assert (True, 1) in outcomes and (False, 0) in outcomes and (False, 1) in outcomes
+    assert g["cases"][:, 3].any()                           # and cross-checked matchers
