@@ -463,3 +463,35 @@ def test_front_end_against_the_references_own_frame_loop(golden, cross_check):
     for k in ("track_ids", "track_ids_off", "last_track", "last_frame", "link_keys", "link_xyz",
               "track_keys", "track_len", "leftover_count"):
         np.testing.assert_array_equal(s[k], g[px + "db_" + k], err_msg=k)
+
+
+@pytest.mark.parametrize("nbytes", [32, 100])
+def test_front_end_with_other_descriptor_widths(nbytes):
+    """32-byte (ORB) and 100-byte descriptors through the whole batched flow (8- and
+    32-word packed rows: the second hand-scheduled scan and the compiler-scheduled
+    one): every index array equals the frame-at-a-time restatement."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=4, n_features=500, seed=31, nbytes=nbytes)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(4))]
+    assert frames[0][2].shape[1] == nbytes
+    n_iter = 256
+    rng = np.random.default_rng(9)
+    stereo_o = [po.stereo_stage(cam, f) for f in frames]
+    samples = np.stack([np.stack([rng.choice(len(stereo_o[p]["left_idx"]), 4, replace=False)
+                                  for _ in range(n_iter)]) for p in range(3)]).astype(np.int32)
+    res = TrackingFrontend(cam, n_iter_max=n_iter).run(frames, samples=samples)
+    stereo_ref, pairs_ref = po.run(cam, frames, samples=samples, n_iter_max=n_iter)
+    for f in range(4):
+        got, ref = res.frame(f), stereo_ref[f]
+        for k in ("left_idx", "right_idx", "dist", "inlier_des_left", "pix_left", "pix_right"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"frame {f} {k}")
+        assert len(got["left_idx"]) > 100
+    for p in range(3):
+        got, ref = res.pair(p), pairs_ref[p]
+        for k in ("query_idx", "train_idx", "dist"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"pair {p} {k}")
+        assert (got["mask"] != ref["mask"]).sum() <= 1 or got["best_index"] != ref["best_index"]
+        assert got["mask"].mean() > 0.25
