@@ -44,6 +44,7 @@ enum {
 /* Limits the kernels are built for. */
 #define SLAMHIP_MAX_DESC_BYTES 128      /* descriptor row length in bytes        */
 #define SLAMHIP_MAX_TRAIN_ROWS (1 << 21)/* train rows per pair (packed-key width)*/
+#define SLAMHIP_MAX_L2_DIM 4096         /* floats per row of the L2 matcher      */
 
 int slamhip_version(void);
 const char *slamhip_strerror(int code);
@@ -110,6 +111,25 @@ int slamhip_hamming_knn2_batched(const uint8_t *d_query, int nq_total, const uin
                                  const int32_t *d_q_off, const int32_t *d_t_off, int n_pairs,
                                  int max_nq, int max_nt, int32_t *d_idx2, int32_t *d_dist2,
                                  void *d_workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- */
+/* L2 brute-force k=2 nearest neighbours for float32 descriptors.            */
+/* Replaces cv2.BFMatcher(NORM_L2).match / knnMatch(k=2): the norm the       */
+/* reference selects for descriptors that are not uint8                      */
+/* (frontend/vision/descriptor_matcher.py:23-28; SuperPoint's 256 floats     */
+/* with matcher_type="bf").                                                  */
+/*   distance = sqrt(sum_k (q_k - t_k)^2) as float32: the sum accumulated in */
+/*   float32 in index order, products and additions rounded separately, the  */
+/*   square root correctly rounded; ties -> lowest train index.              */
+/*   d_idx2 [nq*2] int32   : train index of best, second best (-1 if absent) */
+/*   d_dist2[nq*2] float32 : their distances                (-1.0 if absent) */
+/* Rows are `dim` floats long (1..SLAMHIP_MAX_L2_DIM), `row_stride` floats   */
+/* apart.                                                                    */
+/* ------------------------------------------------------------------------- */
+size_t slamhip_l2_knn2_workspace_bytes(int nq, int nt, int dim);
+int slamhip_l2_knn2(const float *d_query, int nq, const float *d_train, int nt, int dim,
+                    int row_stride, int32_t *d_idx2, float *d_dist2, void *d_workspace,
+                    size_t workspace_bytes, void *stream);
 
 /* Lowe ratio test on the k=2 result (loop_closure.py:194, `ratio_test(raw, ratio)`):
  * keep[i] = 1 iff a second neighbour exists and

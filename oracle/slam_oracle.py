@@ -105,6 +105,64 @@ def hamming_knn2_sequential(q: np.ndarray, t: np.ndarray) -> Tuple[np.ndarray, n
     return idx2, dist2
 
 
+def l2_distance_matrix(q: np.ndarray, t: np.ndarray) -> np.ndarray:
+    """(nq, nt) float32 L2 distances the way cv2.BFMatcher(NORM_L2) defines them for
+    float32 descriptors (the norm descriptor_matcher.py:23-28 selects for non-uint8
+    descriptors): sqrt of the sum of squared differences.  The sum runs in float32 in
+    index order with separately rounded products and additions; OpenCV's own order
+    inside its SIMD kernel is unspecified (PARITY UNPINNED in the last bits)."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    t = np.ascontiguousarray(t, dtype=np.float32)
+    acc = np.zeros((q.shape[0], t.shape[0]), dtype=np.float32)
+    for k in range(q.shape[1]):
+        d = q[:, k, None] - t[None, :, k]
+        acc = acc + d * d
+    return np.sqrt(acc)
+
+
+def l2_knn2(q: np.ndarray, t: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Top-2 L2 neighbours per query row, lowest train index on ties.  Returns
+    (idx2 (nq,2) int32, dist2 (nq,2) float32), -1 where there is no neighbour."""
+    nq, nt = q.shape[0], t.shape[0]
+    idx2 = np.full((nq, 2), -1, dtype=np.int32)
+    dist2 = np.full((nq, 2), -1, dtype=np.float32)
+    if nq == 0 or nt == 0:
+        return idx2, dist2
+    d = l2_distance_matrix(q, t)
+    r = np.arange(nq)
+    i1 = d.argmin(axis=1)                      # first occurrence = lowest index
+    idx2[:, 0], dist2[:, 0] = i1, d[r, i1]
+    if nt > 1:
+        d[r, i1] = np.inf
+        i2 = d.argmin(axis=1)
+        idx2[:, 1], dist2[:, 1] = i2, d[r, i2]
+    return idx2, dist2
+
+
+def bf_match_l2(q: np.ndarray, t: np.ndarray, cross_check: bool = False):
+    """cv2.BFMatcher(NORM_L2, crossCheck).match + the reference's stable sort by
+    distance (descriptor_matcher.py:33-34): (query_idx, train_idx int32, dist float32)."""
+    nq, nt = q.shape[0], t.shape[0]
+    if nq == 0 or nt == 0:
+        z = np.zeros(0, np.int32)
+        return z, z, np.zeros(0, np.float32)
+    if not cross_check:
+        idx2, dist2 = l2_knn2(q, t)
+        qi, ti, di = np.arange(nq, dtype=np.int32), idx2[:, 0], dist2[:, 0]
+    else:
+        ridx, rdist = l2_knn2(t, q)            # every train row votes for its nearest query
+        ti = np.full(nq, -1, np.int32)
+        di = np.full(nq, np.inf, np.float32)
+        for j in range(nt):                    # first voter wins ties (strict <, ascending train index)
+            who, dj = ridx[j, 0], rdist[j, 0]
+            if dj < di[who]:
+                di[who], ti[who] = dj, j
+        keep = ti >= 0
+        qi, ti, di = np.flatnonzero(keep).astype(np.int32), ti[keep], di[keep]
+    order = np.argsort(di, kind="stable")
+    return qi[order], ti[order], di[order]
+
+
 def ratio_test(dist2: np.ndarray, ratio: float) -> np.ndarray:
     """keep[i] = second neighbour exists and d1 < ratio * d2 (fp64)."""
     d1 = dist2[:, 0].astype(np.float64)

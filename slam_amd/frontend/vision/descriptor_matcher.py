@@ -1,6 +1,7 @@
 """Descriptor matching behind the reference's `DescriptorMatcher` interface
 (frontend/vision/descriptor_matcher.py of the reference), executed by the
-Hamming top-2 HIP kernel.
+Hamming top-2 HIP kernel for uint8 (binary) descriptors and by the L2 top-2 kernel
+for any other dtype - the reference's own norm selection (`_get_bf`, :23-28).
 
 `match` returns what the reference's call sites consume: a sequence of
 DMatch-like objects sorted by distance (stable, so equal distances stay in
@@ -32,17 +33,47 @@ class DescriptorMatcher:
 
     # ------------------------------------------------------------------ arrays
     @staticmethod
-    def _check_dtype(des):
-        dt = des.dtype
-        if dt not in (np.uint8, torch.uint8):
-            # The reference switches BFMatcher to NORM_L2 for non-uint8 descriptors;
-            # only the Hamming path (binary AKAZE/ORB descriptors) exists here.
-            raise TypeError("only uint8 (binary, Hamming) descriptors are supported")
+    def _is_binary(des) -> bool:
+        """The reference's norm selection (descriptor_matcher.py:23-28): Hamming for
+        uint8 descriptors, L2 for anything else."""
+        return des.dtype in (np.uint8, torch.uint8)
+
+    def _l2_best(self, desL, desR):
+        """(query rows, train index, distance) of the L2 matcher, unsorted; with
+        cross_check the rows without a match are dropped."""
+        if not self.cross_check:
+            idx2, dist2 = kernels.l2_knn2(desL, desR)
+            nq = idx2.shape[0]
+            qi = torch.arange(nq, dtype=torch.int32, device=idx2.device)
+            return qi, idx2[:, 0].contiguous(), dist2[:, 0].contiguous()
+        # crossCheck: every train row votes for its nearest query; a query keeps the
+        # closest voter, the first one on ties (ascending train index)
+        ridx, rdist = kernels.l2_knn2(desR, desL)
+        nq, dev = int(desL.shape[0]), ridx.device
+        who, dj = ridx[:, 0].long(), rdist[:, 0]
+        ok = who >= 0
+        who, dj = who[ok], dj[ok]
+        tj = torch.arange(ridx.shape[0], device=dev)[ok]
+        # key = (distance bits, train index): the smallest key per query wins
+        key = (dj.view(torch.int32).long() << 32) | tj
+        best = torch.full((nq,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
+        best.scatter_reduce_(0, who, key, reduce="amin")
+        keep = best != torch.iinfo(torch.int64).max
+        qi = torch.arange(nq, dtype=torch.int32, device=dev)[keep]
+        ti = (best[keep] & 0xFFFFFFFF).int()
+        di = (best[keep] >> 32).int().view(torch.float32)
+        return qi, ti, di
 
     def match_arrays(self, desL, desR):
-        """(queryIdx, trainIdx, distance) int32 device tensors in sorted order."""
-        self._check_dtype(desL)
-        self._check_dtype(desR)
+        """(queryIdx, trainIdx, distance) device tensors in sorted order; distance is
+        int32 for binary descriptors, float32 for float descriptors."""
+        if not self._is_binary(desL):
+            if len(desL) == 0 or len(desR) == 0:
+                z = torch.zeros(0, dtype=torch.int32, device="cuda")
+                return z, z.clone(), torch.zeros(0, dtype=torch.float32, device="cuda")
+            qi, ti, di = self._l2_best(desL, desR)
+            order = torch.sort(di, stable=True).indices
+            return qi[order], ti[order], di[order]
         if self.cross_check:
             ti, di = kernels.cross_check_match(desL, desR)
         else:
@@ -54,9 +85,9 @@ class DescriptorMatcher:
         return order.int(), ti[order], di[order]
 
     def knn_arrays(self, desL, desR):
-        """(idx2, dist2): (nq,2) int32 device tensors, -1 where absent."""
-        self._check_dtype(desL)
-        self._check_dtype(desR)
+        """(idx2, dist2): (nq,2) device tensors, -1 where absent."""
+        if not self._is_binary(desL):
+            return kernels.l2_knn2(desL, desR)
         return kernels.hamming_knn2(desL, desR)
 
     # ------------------------------------------------- reference-shaped methods
@@ -86,11 +117,14 @@ class DescriptorMatcher:
         good, rejected = [], []
         if len(raw) == 0:
             return good, rejected
-        d = np.full((len(raw), 2), -1, dtype=np.int32)
+        d = np.full((len(raw), 2), -1.0, dtype=np.float64)
         for i, pair in enumerate(raw):
             for j, m in enumerate(pair[:2]):
-                d[i, j] = int(m.distance)
-        keep = kernels.ratio_test(d, ratio).cpu().numpy()
+                d[i, j] = float(m.distance)
+        if np.all(d == np.round(d)):       # Hamming distances: the device kernel
+            keep = kernels.ratio_test(d.astype(np.int32), ratio).cpu().numpy()
+        else:                              # L2 distances (float): the same comparison on the host
+            keep = (d[:, 0] >= 0) & (d[:, 1] >= 0) & (d[:, 0] < ratio * d[:, 1])
         for i, pair in enumerate(raw):
             if len(pair) == 0:
                 continue

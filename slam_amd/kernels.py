@@ -144,6 +144,32 @@ def hamming_knn2_batched(q, t, q_off, t_off, max_nq: Optional[int] = None,
     return idx2, dist2
 
 
+def l2_knn2(q, t) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-2 L2 neighbours of every row of q among the rows of t (float32 descriptors).
+    Returns (idx2 (nq,2) int32, dist2 (nq,2) float32) device tensors, -1 where absent."""
+    q = to_device(q, torch.float32)
+    t = to_device(t, torch.float32)
+    if q.dim() != 2 or t.dim() != 2:
+        raise ValueError("descriptors must be 2-D (rows, floats)")
+    nq, nt = q.shape[0], t.shape[0]
+    if nq > 0 and nt > 0 and q.shape[1] != t.shape[1]:
+        raise ValueError("query and train descriptors differ in length")
+    d = q.shape[1] if nq else (t.shape[1] if nt else 1)
+    idx2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
+    dist2 = torch.empty((nq, 2), dtype=torch.float32, device=q.device)
+    if nq == 0:
+        return idx2, dist2
+    if d < 1:
+        raise ValueError("descriptor length must be >= 1")
+    need = lib.slamhip_l2_knn2_workspace_bytes(nq, nt, d)
+    if need == 0:
+        check(_lib.EUNSUPPORTED, "slamhip_l2_knn2_workspace_bytes")
+    ws = _workspace(need)
+    check(lib.slamhip_l2_knn2(_ptr(q), nq, _ptr(t), nt, d, d, _ptr(idx2), _ptr(dist2), _ptr(ws),
+                              ws.numel(), _stream()), "slamhip_l2_knn2")
+    return idx2, dist2
+
+
 def ratio_test(dist2: torch.Tensor, ratio: float, out=None) -> torch.Tensor:
     dist2 = to_device(dist2, torch.int32)
     nq = dist2.shape[0]

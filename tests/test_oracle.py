@@ -139,3 +139,27 @@ def test_ransac_loop_matches_reference_loop(golden):
         mask = so.hypothesis_mask(K, MR, Rts[best], X, mL, mR, thr)
         np.testing.assert_array_equal(mask, g[k + "_mask"], err_msg=k)
         assert best_count == int(g[k + "_mask"].sum())
+
+
+def test_l2_restatement_is_the_l2_distance():
+    """The float32 L2 restatement (index-order float32 sum, sqrt) against float64
+    arithmetic: same distances to float32 accuracy, same neighbours wherever the float64
+    distances are not nearly tied; an exact duplicate wins with the lowest index."""
+    rng = np.random.default_rng(0)
+    q = rng.normal(size=(50, 96)).astype(np.float32)
+    t = rng.normal(size=(80, 96)).astype(np.float32)
+    t[7] = t[2]
+    q[0] = t[2]
+    d32 = so.l2_distance_matrix(q, t)
+    d64 = np.sqrt(((q[:, None, :].astype(np.float64) - t[None, :, :].astype(np.float64)) ** 2).sum(-1))
+    assert d32.dtype == np.float32 and np.abs(d32 - d64).max() <= 2e-6 * d64.max()
+    idx2, dist2 = so.l2_knn2(q, t)
+    assert idx2[0, 0] == 2 and idx2[0, 1] == 7 and dist2[0, 0] == 0.0
+    order = np.argsort(d64, axis=1, kind="stable")
+    gap = np.take_along_axis(d64, order[:, 2:3], 1)[:, 0] - np.take_along_axis(d64, order[:, 1:2], 1)[:, 0]
+    clear = (gap > 1e-4) & (np.take_along_axis(d64, order[:, 1:2], 1)[:, 0]
+                            - np.take_along_axis(d64, order[:, 0:1], 1)[:, 0] > 1e-4)
+    assert clear.sum() > 30
+    np.testing.assert_array_equal(idx2[clear], order[clear, :2])
+    qi, ti, di = so.bf_match_l2(q, t)
+    assert (np.diff(di) >= 0).all() and sorted(qi.tolist()) == list(range(50))
