@@ -195,16 +195,24 @@ class TrackingFrontend:
         dev = inp.kp_left.device
         i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         f32 = lambda n: torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        # the outputs that must start at zero share one allocation (one fill launch
+        # instead of five: the one-pair online call is bounded by its launches)
+        P = max(F - 1, 1)
+        zsizes = (("st_desc", torch.int32, max(NL * W, 1)), ("pose_ransac", torch.float64, P * 12),
+                  ("pose_refined", torch.float64, P * 12), ("ransac_info", torch.int32, P * 8),
+                  ("tm_mask", torch.uint8, max(NL, 1)))
+        offs, total = [], 0
+        for _, dt, n in zsizes:
+            offs.append(total)
+            total = (total + n * torch.empty(0, dtype=dt).element_size() + 15) // 16 * 16
+        zbuf = torch.zeros(total, dtype=torch.uint8, device=dev)
         t = {
             "st_count": i32(F), "st_left": i32(NL), "st_right": i32(NL), "st_dist": i32(NL),
             "st_xyz": f32(NL * 3), "st_pix_left": f32(NL * 2), "st_pix_right": f32(NL * 2),
-            "st_desc": torch.zeros(max(NL * W, 1), dtype=torch.int32, device=dev),
             "tm_query": i32(NL), "tm_train": i32(NL), "tm_dist": i32(NL),
-            "tm_mask": torch.zeros(max(NL, 1), dtype=torch.uint8, device=dev),
-            "pose_ransac": torch.zeros(max(F - 1, 1) * 12, dtype=torch.float64, device=dev),
-            "pose_refined": torch.zeros(max(F - 1, 1) * 12, dtype=torch.float64, device=dev),
-            "ransac_info": torch.zeros(max(F - 1, 1) * 8, dtype=torch.int32, device=dev),
         }
+        for (name, dt, n), o in zip(zsizes, offs):
+            t[name] = zbuf[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt)
         a = FrontendArgs()
         a.n_frames, a.n_left_total, a.n_right_total = F, NL, NR
         a.max_left = int(np.diff(inp.off_left).max()) if F else 0
