@@ -130,6 +130,16 @@ size_t slamhip_l2_knn2_workspace_bytes(int nq, int nt, int dim);
 int slamhip_l2_knn2(const float *d_query, int nq, const float *d_train, int nt, int dim,
                     int row_stride, int32_t *d_idx2, float *d_dist2, void *d_workspace,
                     size_t workspace_bytes, void *stream);
+/* The float-distance counterparts of slamhip_cross_check, slamhip_ratio_test and
+ * slamhip_sort_by_distance (one segment): crossCheck fold of the train->query result
+ * (d_match_idx[nq] = train row or -1, d_match_dist[nq] = distance or -1.0), Lowe ratio
+ * test on a k=2 result, and the stable order by (distance, row) with unmatched rows
+ * (distance -1.0) last - the `sorted(matches, key=distance)` of descriptor_matcher.py:34. */
+int slamhip_l2_cross_check(const int32_t *d_t2q_idx2, const float *d_t2q_dist2, int nt, int nq,
+                           int32_t *d_match_idx, float *d_match_dist, void *stream);
+int slamhip_ratio_test_f32(const float *d_dist2, int nq, double ratio, uint8_t *d_keep, void *stream);
+int slamhip_sort_by_distance_f32(const float *d_dist, int dist_stride, int n, int32_t *d_order,
+                                 void *stream);
 
 /* Lowe ratio test on the k=2 result (loop_closure.py:194, `ratio_test(raw, ratio)`):
  * keep[i] = 1 iff a second neighbour exists and

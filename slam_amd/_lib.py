@@ -56,6 +56,9 @@ SIGNATURES = {
     "slamhip_ratio_test": (_i, [_vp, _i, _d, _vp, _vp]),
     "slamhip_l2_knn2_workspace_bytes": (_sz, [_i, _i, _i]),
     "slamhip_l2_knn2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    "slamhip_l2_cross_check": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "slamhip_ratio_test_f32": (_i, [_vp, _i, _d, _vp, _vp]),
+    "slamhip_sort_by_distance_f32": (_i, [_vp, _i, _i, _vp, _vp]),
     "slamhip_cross_check": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "slamhip_sort_by_distance": (_i, [_vp, _i, _i, _vp, _i, _i, _vp, _vp]),
     "slamhip_stereo_filter_triangulate": (

@@ -144,6 +144,61 @@ __global__ __launch_bounds__(256) void l2_merge_kernel(const ulonglong2 *__restr
   dist2[2 * row + 1] = b2 == kNone ? -1.0f : __uint_as_float((unsigned)(b2 >> 32));
 }
 
+// crossCheck=True fold for float distances: one thread per query row scans the
+// train -> query result in ascending train order and keeps the closest train row that
+// chose it, the first one on ties (the fold of cv2's batchDistance).
+__global__ __launch_bounds__(256) void l2_cross_check_kernel(const int32_t *__restrict__ t2q_idx2,
+                                                             const float *__restrict__ t2q_dist2,
+                                                             int nt, int nq,
+                                                             int32_t *__restrict__ match_idx,
+                                                             float *__restrict__ match_dist) {
+  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
+  if (qi >= nq) return;
+  int best_t = -1;
+  float best_d = 0.0f;
+  for (int t = 0; t < nt; ++t) {
+    const int who = t2q_idx2[2 * t];  // wave-uniform address
+    const float d = t2q_dist2[2 * t];
+    if (who == qi && (best_t < 0 || d < best_d)) {
+      best_d = d;
+      best_t = t;
+    }
+  }
+  match_idx[qi] = best_t;
+  match_dist[qi] = best_t < 0 ? -1.0f : best_d;
+}
+
+__global__ __launch_bounds__(256) void l2_ratio_test_kernel(const float *__restrict__ dist2, int nq,
+                                                            double ratio, uint8_t *__restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const float2 d = reinterpret_cast<const float2 *>(dist2)[i];
+  keep[i] = (d.x >= 0.0f && d.y >= 0.0f && (double)d.x < ratio * (double)d.y) ? 1 : 0;
+}
+
+// Stable order by (distance, row) through rank counting on the keys (distance bits,
+// row): non-negative floats order like their bits, and -1.0 (no match) has a larger bit
+// pattern than any of them, so unmatched rows sort last.  One segment of n rows.
+__global__ __launch_bounds__(256) void l2_rank_sort_kernel(const float *__restrict__ dist, int stride,
+                                                           int n, int32_t *__restrict__ order) {
+  __shared__ uint32_t keys[1024];
+  const int i = blockIdx.x * 256 + (int)threadIdx.x;
+  const uint32_t my = i < n ? __float_as_uint(dist[(size_t)i * stride]) : 0xFFFFFFFFu;
+  int rank = 0;
+  for (int j0 = 0; j0 < n; j0 += 1024) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < 1024; k += 256)
+      keys[k] = j0 + k < n ? __float_as_uint(dist[(size_t)(j0 + k) * stride]) : 0xFFFFFFFFu;
+    __syncthreads();
+    const int lim = min(1024, n - j0);
+    for (int k = 0; k < lim; ++k) {
+      const uint32_t o = keys[k];
+      rank += (o < my || (o == my && j0 + k < i)) ? 1 : 0;
+    }
+  }
+  if (i < n) order[rank] = i;
+}
+
 int l2_splits(int nq, int nt) {
   const int qtiles = slamhip_ceil_div(nq > 0 ? nq : 1, kTQ);
   const int ttiles = slamhip_ceil_div(nt > 0 ? nt : 1, kTT);
@@ -185,6 +240,42 @@ int slamhip_l2_knn2(const float *d_query, int nq, const float *d_train, int nt, 
                        d_idx2, d_dist2);
     SLAMHIP_CHECK_LAUNCH();
   }
+  return SLAMHIP_OK;
+}
+
+int slamhip_l2_cross_check(const int32_t *d_t2q_idx2, const float *d_t2q_dist2, int nt, int nq,
+                           int32_t *d_match_idx, float *d_match_dist, void *stream) {
+  SLAMHIP_BEGIN();
+  if (nt < 0 || nq < 0) return SLAMHIP_EINVAL;
+  if (nq == 0) return SLAMHIP_OK;
+  if (!d_match_idx || !d_match_dist || (nt > 0 && (!d_t2q_idx2 || !d_t2q_dist2))) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(l2_cross_check_kernel, dim3(slamhip_ceil_div(nq, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_t2q_idx2, d_t2q_dist2, nt, nq, d_match_idx, d_match_dist);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_ratio_test_f32(const float *d_dist2, int nq, double ratio, uint8_t *d_keep, void *stream) {
+  SLAMHIP_BEGIN();
+  if (nq < 0) return SLAMHIP_EINVAL;
+  if (nq == 0) return SLAMHIP_OK;
+  if (!d_dist2 || !d_keep) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(l2_ratio_test_kernel, dim3(slamhip_ceil_div(nq, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_dist2, nq, ratio, d_keep);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_sort_by_distance_f32(const float *d_dist, int dist_stride, int n, int32_t *d_order,
+                                 void *stream) {
+  SLAMHIP_BEGIN();
+  if (n < 0 || dist_stride < 1) return SLAMHIP_EINVAL;
+  if (n > SLAMHIP_MAX_TRAIN_ROWS) return SLAMHIP_EUNSUPPORTED;
+  if (n == 0) return SLAMHIP_OK;
+  if (!d_dist || !d_order) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(l2_rank_sort_kernel, dim3(slamhip_ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_dist, dist_stride, n, d_order);
+  SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }
 

@@ -38,32 +38,6 @@ class DescriptorMatcher:
         uint8 descriptors, L2 for anything else."""
         return des.dtype in (np.uint8, torch.uint8)
 
-    def _l2_best(self, desL, desR):
-        """(query rows, train index, distance) of the L2 matcher, unsorted; with
-        cross_check the rows without a match are dropped."""
-        if not self.cross_check:
-            idx2, dist2 = kernels.l2_knn2(desL, desR)
-            nq = idx2.shape[0]
-            qi = torch.arange(nq, dtype=torch.int32, device=idx2.device)
-            return qi, idx2[:, 0].contiguous(), dist2[:, 0].contiguous()
-        # crossCheck: every train row votes for its nearest query; a query keeps the
-        # closest voter, the first one on ties (ascending train index)
-        ridx, rdist = kernels.l2_knn2(desR, desL)
-        nq, dev = int(desL.shape[0]), ridx.device
-        who, dj = ridx[:, 0].long(), rdist[:, 0]
-        ok = who >= 0
-        who, dj = who[ok], dj[ok]
-        tj = torch.arange(ridx.shape[0], device=dev)[ok]
-        # key = (distance bits, train index): the smallest key per query wins
-        key = (dj.view(torch.int32).long() << 32) | tj
-        best = torch.full((nq,), torch.iinfo(torch.int64).max, dtype=torch.int64, device=dev)
-        best.scatter_reduce_(0, who, key, reduce="amin")
-        keep = best != torch.iinfo(torch.int64).max
-        qi = torch.arange(nq, dtype=torch.int32, device=dev)[keep]
-        ti = (best[keep] & 0xFFFFFFFF).int()
-        di = (best[keep] >> 32).int().view(torch.float32)
-        return qi, ti, di
-
     def match_arrays(self, desL, desR):
         """(queryIdx, trainIdx, distance) device tensors in sorted order; distance is
         int32 for binary descriptors, float32 for float descriptors."""
@@ -71,9 +45,15 @@ class DescriptorMatcher:
             if len(desL) == 0 or len(desR) == 0:
                 z = torch.zeros(0, dtype=torch.int32, device="cuda")
                 return z, z.clone(), torch.zeros(0, dtype=torch.float32, device="cuda")
-            qi, ti, di = self._l2_best(desL, desR)
-            order = torch.sort(di, stable=True).indices
-            return qi[order], ti[order], di[order]
+            if self.cross_check:
+                ti, di = kernels.l2_cross_check_match(desL, desR)
+            else:
+                idx2, dist2 = kernels.l2_knn2(desL, desR)
+                ti, di = idx2[:, 0].contiguous(), dist2[:, 0].contiguous()
+            order = kernels.sort_by_distance_f32(di)      # unmatched rows (-1) sort last
+            n_valid = int((ti >= 0).sum().item())
+            order = order[:n_valid].long()
+            return order.int(), ti[order], di[order]
         if self.cross_check:
             ti, di = kernels.cross_check_match(desL, desR)
         else:
@@ -123,8 +103,8 @@ class DescriptorMatcher:
                 d[i, j] = float(m.distance)
         if np.all(d == np.round(d)):       # Hamming distances: the device kernel
             keep = kernels.ratio_test(d.astype(np.int32), ratio).cpu().numpy()
-        else:                              # L2 distances (float): the same comparison on the host
-            keep = (d[:, 0] >= 0) & (d[:, 1] >= 0) & (d[:, 0] < ratio * d[:, 1])
+        else:                              # L2 distances (float32)
+            keep = kernels.ratio_test_f32(d.astype(np.float32), ratio).cpu().numpy()
         for i, pair in enumerate(raw):
             if len(pair) == 0:
                 continue

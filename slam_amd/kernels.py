@@ -170,6 +170,40 @@ def l2_knn2(q, t) -> Tuple[torch.Tensor, torch.Tensor]:
     return idx2, dist2
 
 
+def l2_cross_check_match(q, t) -> Tuple[torch.Tensor, torch.Tensor]:
+    """crossCheck=True matching under L2: (train index (nq,) int32, distance (nq,) float32),
+    -1 where a query row has no match."""
+    q = to_device(q, torch.float32)
+    t = to_device(t, torch.float32)
+    nq, nt = q.shape[0], t.shape[0]
+    ridx, rdist = l2_knn2(t, q)
+    mi = torch.empty(nq, dtype=torch.int32, device=q.device)
+    md = torch.empty(nq, dtype=torch.float32, device=q.device)
+    check(lib.slamhip_l2_cross_check(_ptr(ridx), _ptr(rdist), nt, nq, _ptr(mi), _ptr(md), _stream()),
+          "slamhip_l2_cross_check")
+    return mi, md
+
+
+def ratio_test_f32(dist2, ratio: float) -> torch.Tensor:
+    """Lowe ratio test on a float (nq,2) k=2 result: uint8 keep flags."""
+    dist2 = to_device(dist2, torch.float32).contiguous()
+    n = dist2.shape[0]
+    keep = torch.empty(n, dtype=torch.uint8, device=dist2.device)
+    check(lib.slamhip_ratio_test_f32(_ptr(dist2), n, float(ratio), _ptr(keep), _stream()),
+          "slamhip_ratio_test_f32")
+    return keep
+
+
+def sort_by_distance_f32(dist: torch.Tensor) -> torch.Tensor:
+    """Stable order of float distances (unmatched rows, -1.0, last): (n,) int32."""
+    dist = to_device(dist, torch.float32).contiguous()
+    n = dist.shape[0]
+    order = torch.empty(n, dtype=torch.int32, device=dist.device)
+    check(lib.slamhip_sort_by_distance_f32(_ptr(dist), 1, n, _ptr(order), _stream()),
+          "slamhip_sort_by_distance_f32")
+    return order
+
+
 def ratio_test(dist2: torch.Tensor, ratio: float, out=None) -> torch.Tensor:
     dist2 = to_device(dist2, torch.int32)
     nq = dist2.shape[0]
