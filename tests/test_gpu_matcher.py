@@ -179,6 +179,35 @@ def test_seeded_random_shapes_strides_and_knobs():
         _lib.lib.slamhip_tune(3, 0)
 
 
+def test_maximum_train_rows(oracle_c):
+    """The largest train set the packed keys allow (2^21 rows, the index field of a key):
+    the best match planted in the very last row, an exact duplicate of another query's
+    match earlier on (tie: the lower index wins), the rest random; against the C
+    restatement.  One row more is refused."""
+    import ctypes as C
+    from slam_amd import _lib, kernels
+    rng = np.random.default_rng(2021)
+    nt, nq, d = 1 << 21, 70, 61
+    t = rng.integers(0, 256, (nt, d), dtype=np.uint8)
+    q = rng.integers(0, 256, (nq, d), dtype=np.uint8)
+    q[0] = t[nt - 1]                    # distance 0 at the highest index a key can hold
+    t[nt - 7] = t[5]
+    q[1] = t[5]                         # two rows at distance 0: index 5 first, then 2^21 - 7
+    i, dd = _run(q, t)
+    ei, ed = oracle_c(q, t, threads=8)
+    np.testing.assert_array_equal(i, ei)
+    np.testing.assert_array_equal(dd, ed)
+    assert i[0, 0] == nt - 1 and dd[0, 0] == 0
+    assert i[1].tolist() == [5, nt - 7] and dd[1].tolist() == [0, 0]
+    assert _lib.lib.slamhip_hamming_knn2_workspace_bytes(nq, nt, 1, nq, nt, d) > 0
+    tq = torch.zeros((nq, d), dtype=torch.uint8, device="cuda")
+    out = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    rc = _lib.lib.slamhip_hamming_knn2(C.c_void_p(tq.data_ptr()), nq, C.c_void_p(tq.data_ptr()), nt + 1, d, d,
+                                       C.c_void_p(out.data_ptr()), C.c_void_p(out.data_ptr()),
+                                       C.c_void_p(out.data_ptr()), C.c_size_t(1 << 30), None)
+    assert rc == _lib.EUNSUPPORTED
+
+
 def test_empty_inputs():
     q = np.zeros((5, 61), np.uint8)
     i, d = _run(q, np.zeros((0, 61), np.uint8))
