@@ -73,3 +73,56 @@ def test_descriptor_matcher_with_float_descriptors(cross_check):
     keep = edd[:, 0].astype(np.float64) < 0.7 * edd[:, 1].astype(np.float64)
     assert [g.queryIdx for g in good] == np.flatnonzero(keep).tolist()
     assert len(good) + len(rejected) == 300 and 0 < len(good) < 300
+
+
+def test_l2_equal_rounded_distances_from_different_sums():
+    """Sums of squares 1 + 2 ulp and 1 + 3 ulp have the same rounded square root
+    (1 + 1 ulp): the order among them is by train index, not by sum, and a second
+    neighbour with the larger sum must not be displaced by a later row with the smaller."""
+    from slam_amd import kernels
+    z = np.float32(2.0 ** -11.5)
+    hi = [1.0, 2.0 ** -11, z, 0.0]          # 1 + 2^-22 + ~2^-23 -> 1 + 3 ulp
+    lo = [1.0, 2.0 ** -11, 0.0, 0.0]        # 1 + 2 ulp
+    far = [3.0, 0.0, 0.0, 0.0]
+    for rows, expect in [([hi, lo, lo, far], (0, 1)), ([far, lo, hi, lo], (1, 2)), ([hi, far, hi, lo], (0, 2)),
+                         ([lo] + [far] * 300 + [hi, lo], (0, 301))]:
+        t = np.array(rows, np.float32)
+        q = np.zeros((3, 4), np.float32)
+        acc = (t.astype(np.float32) ** 2)
+        s = ((acc[:, 0] + acc[:, 1]) + acc[:, 2]) + acc[:, 3]
+        assert len({float(np.sqrt(v)) for v in s[s < 2]}) == 1 and len({float(v) for v in s[s < 2]}) == 2
+        i, d = kernels.l2_knn2(q, t)
+        torch.cuda.synchronize()
+        ei, ed = so.l2_knn2(q, t)
+        np.testing.assert_array_equal(i.cpu().numpy(), ei)
+        np.testing.assert_array_equal(d.cpu().numpy(), ed)
+        assert tuple(ei[0]) == expect
+
+
+def test_l2_strided_and_unaligned_rows():
+    """Rows inside wider rows (row_stride > dim) and a base address that is not a
+    multiple of 16 bytes: the kernel falls back from 16-byte loads; same result."""
+    from slam_amd import _lib, kernels
+    rng = np.random.default_rng(8)
+    nq, nt, d, stride = 150, 333, 64, 71
+    Q = rng.normal(size=(nq, stride)).astype(np.float32)
+    T = rng.normal(size=(nt, stride)).astype(np.float32)
+    ei, ed = so.l2_knn2(np.ascontiguousarray(Q[:, 3:3 + d]), np.ascontiguousarray(T[:, 3:3 + d]))
+    dq, dt = torch.from_numpy(Q).cuda(), torch.from_numpy(T).cuda()
+    idx2 = torch.empty((nq, 2), dtype=torch.int32, device="cuda")
+    dist2 = torch.empty((nq, 2), dtype=torch.float32, device="cuda")
+    need = _lib.lib.slamhip_l2_knn2_workspace_bytes(nq, nt, d)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    rc = _lib.lib.slamhip_l2_knn2(dq.data_ptr() + 12, nq, dt.data_ptr() + 12, nt, d, stride, idx2.data_ptr(),
+                                  dist2.data_ptr(), ws.data_ptr(), need, 0)
+    assert rc == 0
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(idx2.cpu().numpy(), ei)
+    np.testing.assert_array_equal(dist2.cpu().numpy(), ed)
+    # aligned rows of a multiple of four floats (the 16-byte path), many tiles per block
+    q, t = _desc(rng, 300, 256), _desc(rng, 3000, 256)
+    i, dd = kernels.l2_knn2(q, t)
+    torch.cuda.synchronize()
+    ei, ed = so.l2_knn2(q, t)
+    np.testing.assert_array_equal(i.cpu().numpy(), ei)
+    np.testing.assert_array_equal(dd.cpu().numpy(), ed)
