@@ -19,6 +19,7 @@ stats bench_matcher8k -- python3 bench.py --steps 400 --warmup 20 $MARGS
 stats frontend500 -- python3 tools/profile_frontend.py 500 1500
 stats frontend_envelope60 -- python3 tools/profile_frontend.py 60 2000 8000
 stats loop_verify270 -- python3 tools/profile_loop_verify.py 270
+stats l2_8k -- python3 tools/profile_l2.py 8192 256 10
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_SALU"; do
   name=$(echo $grp | cut -d' ' -f1)
   timeout -s KILL 120 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pmc_$name -- python3 bench.py --steps 20 --warmup 5 $MARGS > /dev/null 2>> $OUT/prof_tmp.err
