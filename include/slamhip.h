@@ -252,12 +252,18 @@ int slamhip_refine_pose(const void *d_points, int points_fp64, const float *d_pi
 /* The two small helpers the reference exposes on its own:
  * PnP.project (pnp.py:94-99): pixels (n,2) fp64 = dehomogenised P @ [X,1];
  * P is a HOST pointer to 12 doubles.  PnP.supporters_pair (pnp.py:86-91) with
- * compute_err (utils/graph_utils.py:7-11): all inputs (n,2) fp64 on the device. */
+ * compute_err (utils/graph_utils.py:7-11): all inputs (n,2) fp64 on the device;
+ * errors are computed like slamhip_compute_err does. */
 int slamhip_project(const void *d_points, int points_fp64, int n, const double *P,
                     double *d_pixels, void *stream);
 int slamhip_supporters_pair(const double *d_meas_l, const double *d_proj_l,
                             const double *d_meas_r, const double *d_proj_r, int n,
                             double thresh, uint8_t *d_mask, void *stream);
+/* compute_err on its own (utils/graph_utils.py:7-11): d_err[i] = the Euclidean distance
+ * between pixel rows i of two (n,2) fp64 device arrays, sqrt(dx*dx + dy*dy) with every
+ * step rounded separately (what np.linalg.norm(meas - proj, axis=1) computes). */
+int slamhip_compute_err(const double *d_meas, const double *d_proj, int n, double *d_err,
+                        void *stream);
 
 /* Sequential replay of the adaptive stopping rule of pnp.py:123-158 over the
  * ordered hypothesis counts (count < 0 = failed solve, iteration still

@@ -69,6 +69,7 @@ SIGNATURES = {
     "slamhip_refine_pose": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _dp, _vp, _i, _vp, _vp, _vp]),
     "slamhip_project": (_i, [_vp, _i, _i, _dp, _vp, _vp]),
     "slamhip_supporters_pair": (_i, [_vp, _vp, _vp, _vp, _i, _d, _vp, _vp]),
+    "slamhip_compute_err": (_i, [_vp, _vp, _i, _vp, _vp]),
     "slamhip_ransac_replay": (_i, [_vp, _i, _i, _d, _i, _i, _vp, _vp]),
 }
 

@@ -166,9 +166,11 @@ __global__ __launch_bounds__(256) void project_kernel(const PT *__restrict__ pts
   const double Y = (double)pts[3 * (size_t)p + 1];
   const double Z = (double)pts[3 * (size_t)p + 2];
   const double *P = pr.P;
-  const double x = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[0], X), __dmul_rn(P[1], Y)), __dmul_rn(P[2], Z)), P[3]);
-  const double y = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[4], X), __dmul_rn(P[5], Y)), __dmul_rn(P[6], Z)), P[7]);
-  const double w = __dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(P[8], X), __dmul_rn(P[9], Y)), __dmul_rn(P[10], Z)), P[11]);
+  // The reference's P @ [X,1] goes through its BLAS, whose rounding (fused or not, and in
+  // which order) is not specified; here: fused multiply-adds in column order.
+  const double x = fma(P[2], Z, fma(P[1], Y, fma(P[0], X, P[3])));
+  const double y = fma(P[6], Z, fma(P[5], Y, fma(P[4], X, P[7])));
+  const double w = fma(P[10], Z, fma(P[9], Y, fma(P[8], X, P[11])));
   out[2 * (size_t)p + 0] = x / w;
   out[2 * (size_t)p + 1] = y / w;
 }
@@ -179,14 +181,31 @@ __global__ __launch_bounds__(256) void supporters_kernel(const double *__restric
                                                          const double *__restrict__ mR,
                                                          const double *__restrict__ pR, int n,
                                                          double thr, uint8_t *__restrict__ mask) {
+  // no contraction of dx*dx + dy*dy into a fused multiply-add (NumPy rounds each step);
+  // plain operators, because the pragma does not reach the __dmul_rn / __dadd_rn intrinsics
+#pragma clang fp contract(off)
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const size_t i = 2 * (size_t)p;
-  const double ax = __dsub_rn(mL[i], pL[i]), ay = __dsub_rn(mL[i + 1], pL[i + 1]);
-  const double bx = __dsub_rn(mR[i], pR[i]), by = __dsub_rn(mR[i + 1], pR[i + 1]);
-  const double eL = sqrt(__dadd_rn(__dmul_rn(ax, ax), __dmul_rn(ay, ay)));
-  const double eR = sqrt(__dadd_rn(__dmul_rn(bx, bx), __dmul_rn(by, by)));
+  const double ax = mL[i] - pL[i], ay = mL[i + 1] - pL[i + 1];
+  const double bx = mR[i] - pR[i], by = mR[i + 1] - pR[i + 1];
+  const double eL = sqrt(ax * ax + ay * ay);
+  const double eR = sqrt(bx * bx + by * by);
   mask[p] = (eL <= thr && eR <= thr) ? 1 : 0;
+}
+
+// compute_err (utils/graph_utils.py:7-11): np.linalg.norm(meas - proj, axis=1) for (n,2)
+// fp64 arrays = sqrt(dx*dx + dy*dy), each step rounded on its own, the root correctly rounded.
+__global__ __launch_bounds__(256) void compute_err_kernel(const double *__restrict__ meas,
+                                                          const double *__restrict__ proj, int n,
+                                                          double *__restrict__ err) {
+#pragma clang fp contract(off)
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const size_t i = 2 * (size_t)p;
+  const double dx = meas[i] - proj[i], dy = meas[i + 1] - proj[i + 1];
+  const double sx = dx * dx, sy = dy * dy;
+  err[p] = __dsqrt_rn(sx + sy);
 }
 
 void fill_cam(RansacCam &cam, const double *K, const double *M_right) {
@@ -282,6 +301,18 @@ int slamhip_project(const void *d_points, int points_fp64, int n, const double *
   else
     hipLaunchKernelGGL(project_kernel<float>, grid, block, 0, (hipStream_t)stream,
                        (const float *)d_points, n, pr, d_pixels);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_compute_err(const double *d_meas, const double *d_proj, int n, double *d_err,
+                        void *stream) {
+  SLAMHIP_BEGIN();
+  if (n < 0) return SLAMHIP_EINVAL;
+  if (n == 0) return SLAMHIP_OK;
+  if (!d_meas || !d_proj || !d_err) return SLAMHIP_EINVAL;
+  hipLaunchKernelGGL(compute_err_kernel, dim3(slamhip_ceil_div(n, 256)), dim3(256), 0,
+                     (hipStream_t)stream, d_meas, d_proj, n, d_err);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

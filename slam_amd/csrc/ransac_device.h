@@ -52,9 +52,13 @@ __device__ __forceinline__ double threshold_squared(double thr) { return thr >= 
 // Literal reference sequence for one camera (used for borderline points only).
 __device__ __forceinline__ bool inlier_exact(double x, double y, double w, double mu, double mv,
                                           double thr) {
+  // every operation rounded on its own, as NumPy does it: hipcc would otherwise contract
+  // dx*dx + dy*dy into a fused multiply-add (it does so through __dmul_rn / __dadd_rn too,
+  // which the pragma does not reach: plain operators)
+#pragma clang fp contract(off)
   const double u = x / w, v = y / w;
-  const double dx = __dsub_rn(mu, u), dy = __dsub_rn(mv, v);
-  const double e = sqrt(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)));
+  const double dx = mu - u, dy = mv - v;
+  const double e = sqrt(dx * dx + dy * dy);
   return e <= thr;  // NaN (w == 0) compares false, as in NumPy
 }
 

@@ -33,6 +33,23 @@ class PnP:
         self.pixel_thresh = pixel_thresh
 
     # --------------------------------------------------------------- solve_pnp
+    def _rotation_vec_to_mat(self, R_vec, t_vec):
+        """[R|t] (3,4) from a rotation vector and a translation (pnp.py:29-33; the
+        reference calls cv2.Rodrigues).  Host arithmetic on three numbers: the device
+        solvers hand out [R|t] directly and never go through a rotation vector; this is
+        here for callers that hold one."""
+        r = np.asarray(R_vec, dtype=np.float64).reshape(3)
+        t = np.asarray(t_vec, dtype=np.float64).reshape(3, 1)
+        theta = float(np.linalg.norm(r))
+        if theta < np.finfo(np.float64).eps:
+            R = np.eye(3)
+        else:
+            k = r / theta
+            Kx = np.array([[0.0, -k[2], k[1]], [k[2], 0.0, -k[0]], [-k[1], k[0], 0.0]])
+            c, s_ = np.cos(theta), np.sin(theta)
+            R = c * np.eye(3) + (1.0 - c) * np.outer(k, k) + s_ * Kx
+        return np.hstack((R, t))
+
     def solve_pnp(self, obj_pts, img_pts, flag):
         """3x4 [R|t] or None.  flag = SOLVEPNP_AP3P: minimal solve from the first
         three correspondences, the fourth picks the root.  flag =

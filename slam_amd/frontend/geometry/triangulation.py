@@ -52,6 +52,18 @@ class Triangulation:
             self.P_left, self.P_right, do_filter=False, fp64=False)
         return xyz.cpu().numpy()
 
+    # The two builders of the reference's own DLT (triangulation.py:32-46), for callers
+    # that assemble a system themselves.  triangulate_matches_batched below does not go
+    # through them: the kernel builds every point's 4 x 4 system in registers.
+    def _build_single_camera_A_matrix(self, x_pix, y_pix, camera_matrix):
+        """(2,4) block of one camera for one point: rows y*P[2] - P[1] and P[0] - x*P[2]."""
+        P = np.asarray(camera_matrix, dtype=np.float64)
+        return np.vstack([(y_pix * P[2]) - P[1], P[0] - (x_pix * P[2])])
+
+    def _build_A_matrix(self, A1, A2):
+        """(4,4) system of one point from the two cameras' blocks."""
+        return np.vstack([A1, A2])
+
     def triangulate_matches_batched(self, kps_left, kps_right, matches):
         """(N,3) float64 points: the reference's own least-squares DLT.  Same
         null space as triangulate_opencv's system, kept in fp64 throughout."""

@@ -355,6 +355,17 @@ def supporters_pair(meas_l, proj_l, meas_r, proj_r, thresh: float) -> torch.Tens
     return mask
 
 
+def compute_err(meas, proj) -> torch.Tensor:
+    """Per-row Euclidean distance between two (n,2) pixel arrays, fp64 device tensor (n,)."""
+    m = to_device(meas, torch.float64)
+    p = to_device(proj, torch.float64)
+    if m.dim() != 2 or m.shape[1] != 2 or m.shape != p.shape:
+        raise ValueError("compute_err takes two (n, 2) arrays of the same length")
+    err = torch.empty((m.shape[0],), dtype=torch.float64, device=m.device)
+    check(lib.slamhip_compute_err(_ptr(m), _ptr(p), m.shape[0], _ptr(err), _stream()), "slamhip_compute_err")
+    return err
+
+
 def p3p_solve_indexed(points, pixels, idx4, K):
     """Minimal pose per row of idx4 (h,4) into points (n,3) / pixels (n,2).
     Returns (Rts (h,3,4) fp64, valid (h,) uint8) on the device."""

@@ -50,6 +50,34 @@ def test_project_and_supporters_match_reference_golden(golden):
         np.testing.assert_array_equal(m.cpu().numpy(), g["masks"][h])
 
 
+def test_compute_err_equals_the_references_bit_for_bit(golden):
+    """compute_err (utils/graph_utils.py:7-11) on the projections the reference computed:
+    the errors it computed from them, every bit (no fused multiply-add in dx*dx + dy*dy);
+    and the supporters mask from those same errors."""
+    from slam_amd import kernels
+    from slam_amd.utils.graph_utils import compute_err
+    g = golden("ref_ransac_score.npz")
+    thr = float(g["pixel_thresh"])
+    n_checked = 0
+    for h in range(len(g["Rts"])):
+        for meas, proj, ref in ((g["meas_L"], g["proj_L"][h], g["err_L"][h]), (g["meas_R"], g["proj_R"][h], g["err_R"][h])):
+            err = compute_err(meas.astype(np.float64), proj)
+            assert isinstance(err, np.ndarray) and err.dtype == np.float64
+            ok = np.isfinite(ref)
+            np.testing.assert_array_equal(err[ok], ref[ok])
+            assert (np.isnan(err) == np.isnan(ref)).all()
+            n_checked += int(ok.sum())
+        m = kernels.supporters_pair(g["meas_L"], g["proj_L"][h], g["meas_R"], g["proj_R"][h], thr).cpu().numpy()
+        np.testing.assert_array_equal(m.astype(bool), (g["err_L"][h] <= thr) & (g["err_R"][h] <= thr))
+    assert n_checked > 5000
+    dev = compute_err(torch.from_numpy(g["meas_L"].astype(np.float64)).cuda(), torch.from_numpy(g["proj_L"][0]).cuda())
+    assert dev.is_cuda and dev.shape == (len(g["meas_L"]),)
+    # random pairs against NumPy's own norm (separately rounded squares, correctly rounded root)
+    rng = np.random.default_rng(0)
+    a, b = rng.normal(0, 300, (20000, 2)), rng.normal(0, 300, (20000, 2))
+    np.testing.assert_array_equal(compute_err(a, b), np.linalg.norm(a - b, axis=1))
+
+
 def test_scores_large_random_scene_with_invalid_hypotheses():
     from slam_amd import kernels, CameraModel
     from slam_amd.utils.synth import perturbed_hypotheses
