@@ -233,6 +233,28 @@ def bench_sweep(kernels):
     return rows
 
 
+def bench_l2(kernels):
+    """The matcher's other branch (float32 descriptors, L2 norm: what SuperPoint's 256
+    floats get with matcher_type="bf"), one 8192 x 8192 pair resident in HBM."""
+    n, dim, reps = 8192, 256, 10
+    g = torch.Generator().manual_seed(0)
+    t = torch.randn((n, dim), generator=g)
+    q = (t[torch.randperm(n, generator=g)] + 0.05 * torch.randn((n, dim), generator=g)).cuda()
+    t = t.cuda()
+    for _ in range(3):
+        kernels.l2_knn2(q, t)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        kernels.l2_knn2(q, t)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"metric": "l2_compares_per_sec", "value": n * n / dt, "unit": "compares/s", "n": n, "dim": dim,
+            "us_per_call": dt * 1e6, "dtype": "f32 (subtract, multiply, add; no FMA)",
+            "lane_ops_per_sec": 3.0 * n * n * dim / dt,
+            "frac_of_2_cycle_valu_rate": 3.0 * n * n * dim / dt / UNIFORM_PEAK_LANE_OPS}
+
+
 def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
     """Secondary measurement (BASELINE.json configs[4] shape): descriptor matching +
     PnP-RANSAC consensus + refinement for ALL pairs of `--lc-keyframes` synthetic
@@ -459,6 +481,7 @@ def main():
         }
         if world == 1 and not args.no_sweep:
             line["sweep"] = bench_sweep(kernels)
+            line["l2_matcher"] = bench_l2(kernels)
         if frontend is not None:
             line["frontend"] = frontend
         if loop_verify is not None:
