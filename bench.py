@@ -27,6 +27,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -350,6 +351,8 @@ def main():
     ap.add_argument("--envelope-frames", type=int, default=60,
                     help="frames of the 2000-8000 features/image front-end measurement (0 = skip)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the matcher size sweep")
+    ap.add_argument("--section-timeout", type=float, default=300.0,
+                    help="seconds the secondary sections (front-end, loop verification) may take together")
     ap.add_argument("--lc-keyframes", type=int, default=270,
                     help="keyframes of the secondary loop-closure verification measurement (0 = skip)")
     args = ap.parse_args()
@@ -433,14 +436,7 @@ def main():
     n_launch = _lib.lib.slamhip_profile_end(C.byref(total_ms))
     kernel_s = (total_ms.value / max(n_launch, 1)) * 1e-3
 
-    frontend = None
-    if args.frames >= 2:
-        frontend = bench_frontend(args, rank, world, dist, red_dev)
-
-    loop_verify = None
-    if args.lc_keyframes >= 2:
-        loop_verify = bench_loop_verify(args, rank, world, dist, red_dev)
-
+    line = None
     if rank == 0:
         compares = float(NQ) * NT
         achieved = compares * OPS_PER_COMPARE / kernel_s
@@ -479,6 +475,38 @@ def main():
                                          "(profiles/r1/pmc_matcher8k_t.txt); includes the 4 MB of "
                                          "split results the kernel writes for the merge"},
         }
+    # The secondary sections exchange records between ranks.  The primary measurement is
+    # complete at this point: if a section fails on one rank (the others would then wait in
+    # a collective for ever) or does not finish in time, rank 0 still prints the line, with
+    # what went wrong, and every rank ends.
+    def abandon():
+        if rank == 0:
+            line["secondary_sections"] = f"abandoned after {args.section_timeout} s"
+            print(json.dumps(line), flush=True)
+        os._exit(0)
+    watchdog = threading.Timer(args.section_timeout, abandon)
+    watchdog.daemon = True
+    watchdog.start()
+    failed = {}
+    frontend = loop_verify = None
+    try:
+        if args.frames >= 2:
+            frontend = bench_frontend(args, rank, world, dist, red_dev)
+    except Exception as e:  # noqa: BLE001
+        failed["frontend"] = repr(e)
+    try:
+        if args.lc_keyframes >= 2 and not failed:
+            loop_verify = bench_loop_verify(args, rank, world, dist, red_dev)
+    except Exception as e:  # noqa: BLE001
+        failed["loop_verify"] = repr(e)
+    if failed and world > 1 and rank != 0:
+        # leaving now would make the launcher stop rank 0 before it has printed: stay until
+        # the watchdog ends this process
+        while True:
+            time.sleep(1.0)
+    watchdog.cancel()
+
+    if rank == 0:
         if world == 1 and not args.no_sweep:
             line["sweep"] = bench_sweep(kernels)
             line["l2_matcher"] = bench_l2(kernels)
@@ -486,6 +514,8 @@ def main():
             line["frontend"] = frontend
         if loop_verify is not None:
             line["loop_verify"] = loop_verify
+        if failed:
+            line["secondary_sections_failed"] = failed
         if world == 1 and not args.no_cpu_baseline:
             res = cpu_baseline(q_np, t_np)
             if res is not None:
@@ -496,6 +526,8 @@ def main():
                 line["parity_vs_cpu_port"] = bool((idx2.cpu().numpy() == ci).all() and
                                                   (dist2.cpu().numpy() == cd).all())
         print(json.dumps(line), flush=True)
+    if failed and world > 1:
+        os._exit(0)                          # the other ranks may be inside a collective
     if dist is not None:
         dist.destroy_process_group()
 
