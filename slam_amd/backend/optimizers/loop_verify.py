@@ -8,7 +8,7 @@ flag, relative pose, inlier mask and the matches.
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 import torch

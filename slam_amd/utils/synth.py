@@ -6,7 +6,7 @@ descriptor bit noise and clutter.  Pure NumPy; produces inputs only.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import Tuple
 
 import numpy as np
 
