@@ -112,6 +112,7 @@ class PairVerifier:
         des = np.concatenate([np.asarray(k[1], dtype=np.uint8) for k in keyframes])
         kp_l = np.ascontiguousarray(links[:, [0, 2]])
         kp_r = np.ascontiguousarray(links[:, [1, 2]])
+        self._kf_host = (kp_l.astype(np.float32), off)      # left pixels as cv2.KeyPoint keeps them
         self._kf = {"n": np.asarray(n, dtype=np.int64), "off": off,
                     "kp_l": kernels.to_device(kp_l, torch.float64),
                     "kp_r": kernels.to_device(kp_r, torch.float64),
@@ -195,3 +196,32 @@ class PairVerifier:
             "out_off": obase,
         }
         return VerifyResult(host, out, O, N)
+
+    def consensus_pnp_match(self, kf_curr: int, kf_cand: int, pose_factory=None):
+        """One pair, shaped like the reference's method (loop_closure.py:167-235):
+        (True, Delta_inv, mask, (kf_curr, kf_cand), px) or (False, None, None, (None, None), {}).
+        kf_curr / kf_cand index the list given to set_keyframes.  Delta_inv is
+        `pose_factory(R, t).inverse()` when a factory is given (the reference builds
+        gtsam.Pose3(gtsam.Rot3(R), gtsam.Point3(t)), loop_closure.py:226-228), else the
+        inverse pose as a 4 x 4 array.  px holds the left pixels of inlier and outlier
+        matches in both keyframes (float32), as loop_closure.py:230-233.  A caller with many
+        candidates per keyframe should hand all pairs to verify() at once."""
+        res = self.verify(np.array([[kf_cand, kf_curr]], dtype=np.int64))
+        if not bool(res["ok"][0]):
+            return (False, None, None, (None, None), {})
+        m = res.pair_matches(0)
+        mask = m["mask"]
+        kp_l, off = self._kf_host
+        pts_curr = kp_l[off[kf_curr] + m["train_idx"].astype(np.int64)]
+        pts_cand = kp_l[off[kf_cand] + m["query_idx"].astype(np.int64)]
+        Rt = res["Rt"][0]
+        R, t = Rt[:, :3], Rt[:, 3]
+        if pose_factory is not None:
+            delta_inv = pose_factory(R, t).inverse()
+        else:
+            delta_inv = np.eye(4)
+            delta_inv[:3, :3] = R.T
+            delta_inv[:3, 3] = -R.T @ t
+        px = dict(inl_curr=pts_curr[mask], out_curr=pts_curr[~mask],
+                  inl_cand=pts_cand[mask], out_cand=pts_cand[~mask])
+        return (True, delta_inv, mask, (kf_curr, kf_cand), px)

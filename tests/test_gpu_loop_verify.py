@@ -137,6 +137,58 @@ def test_verify_against_the_references_own_consensus_check(golden):
         assert np.abs(D[:3, :3]).max() < 5e-3 and np.abs(D[:3, 3]).max() < 0.15, D
 
 
+def test_single_pair_method_has_the_references_return_shape(golden):
+    """PairVerifier.consensus_pnp_match(kf_curr, kf_cand): the tuple of
+    loop_closure.py:207/235, consistent with verify() on the same pair; the pixel sets are
+    the reference's own where the match lists are (every row of px comes from the same
+    keypoints; which rows are inliers depends on the samples drawn)."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    g = golden("ref_consensus_flow.npz")
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    ids = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("links_"))
+    keyframes = [(g[f"links_{k}"], g[f"des_{k}"]) for k in ids]
+    seen = set()
+    for i, (curr, cand, gate, cc) in enumerate(g["cases"]):
+        ver = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i,
+                           frame_cross_check=bool(cc)).set_keyframes(keyframes)
+        ci, ni = ids.index(int(cand)), ids.index(int(curr))
+        out = ver.consensus_pnp_match(ni, ci)
+        assert len(out) == 5 and out[0] == bool(g[f"ok_{i}"])
+        seen.add(out[0])
+        if not out[0]:
+            assert out[1:] == (None, None, (None, None), {})
+            continue
+        ok, delta_inv, mask, pair, px = out
+        assert pair == (ni, ci) and mask.dtype == bool
+        res = ver.verify(np.array([[ci, ni]], dtype=np.int64))          # same seed, same pair: same result
+        np.testing.assert_array_equal(mask, res.pair_matches(0)["mask"])
+        T = np.eye(4)
+        T[:3] = res["Rt"][0]
+        np.testing.assert_allclose(delta_inv @ T, np.eye(4), atol=1e-12)
+        assert np.abs(delta_inv - g[f"delta_inv_{i}"])[:3, :3].max() < 5e-3
+        assert set(px) == {"inl_curr", "out_curr", "inl_cand", "out_cand"}
+        for k in px:
+            assert px[k].dtype == np.float32 and px[k].shape[1] == 2
+        assert len(px["inl_curr"]) == len(px["inl_cand"]) == mask.sum()
+        assert len(px["out_curr"]) == len(px["out_cand"]) == (~mask).sum()
+        # the union of inlier and outlier pixels is the reference's, whatever the split
+        ref_curr = {tuple(r) for r in g[f"inl_curr_{i}"]}
+        ours_curr = {tuple(r) for r in np.vstack([px["inl_curr"], px["out_curr"]])}
+        assert ref_curr <= ours_curr
+        ref_cand = {tuple(r) for r in g[f"inl_cand_{i}"]}
+        assert ref_cand <= {tuple(r) for r in np.vstack([px["inl_cand"], px["out_cand"]])}
+
+        class Pose:                                                      # what gtsam.Pose3 offers here
+            def __init__(self, R, t):
+                self.R, self.t = R, t
+
+            def inverse(self):
+                return ("inverse of", self.R.shape, self.t.shape)
+        assert ver.consensus_pnp_match(ni, ci, pose_factory=Pose)[1] == ("inverse of", (3, 3), (3,))
+    assert seen == {True, False}
+
+
 def test_verify_pairs_with_cross_checked_matcher():
     """frame_cross_check=True (the matcher of loop_closure.py:192 built with crossCheck):
     fewer matches per pair, the same ones as the CPU restatement, in the same order; the
