@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void load_kernel(unsigned long long *stamps, f
 }
 
 template <int KIND>
-static void run(const char *name, int iters) {
+static void run(const char *name, int iters, int instr_per_iter) {
   const int blocks = 256 * 8;
   unsigned long long *st;
   float *sink;
@@ -69,15 +69,15 @@ static void run(const char *name, int iters) {
     for (int b = 0; b < blocks; ++b) { cyc += (double)h[2 * b]; real += (double)h[2 * b + 1]; }
     printf("%-22s launch %d: %.0f MHz (block time %.0f us, launch %.0f us, %.2f cycles per instruction and SIMD)\n",
            name, rep, cyc / real * 100.0, real / blocks / 100.0, ms * 1e3,
-           ms * 1e-3 * (cyc / real * 1e8) / ((double)blocks * 4 / 1024 * iters * 32));
+           ms * 1e-3 * (cyc / real * 1e8) / ((double)blocks * 4 / 1024 * iters * instr_per_iter));
   }
   hipFree(st);
   hipFree(sink);
 }
 
 int main() {
-  run<0>("packed fp32 fma", 6000);
-  run<1>("xor + popcount", 6000);
-  run<2>("fp64 fma", 6000);
+  run<0>("packed fp32 fma", 6000, 32);      // 32 v_pk_fma_f32 per iteration
+  run<1>("xor + popcount", 6000, 64);       // 32 v_xor_b32 + 32 v_bcnt_u32_b32
+  run<2>("fp64 fma", 6000, 16);             // 16 v_fma_f64
   return 0;
 }
