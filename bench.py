@@ -54,7 +54,7 @@ def peak_compares_per_sec(desc_bytes):
 
 
 PEAK_LANE_OPS = peak_compares_per_sec(DESC_BYTES) * 2 * ((DESC_BYTES + 3) // 4)   # 52.4 T for 61 B
-# HBM-side bytes per top-2 launch from the committed PMC passes (profiles/r1/pmc_matcher8k_u.txt):
+# HBM-side bytes per top-2 launch from the committed PMC passes (profiles/r1/pmc_matcher8k_v.txt):
 # FETCH_SIZE 2327 KB x2 (gfx950 wide-read correction) + WRITE_SIZE 4096 KB.
 PMC_TRAFFIC_BYTES = (2327 * 2 + 4096) * 1024
 OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
@@ -472,7 +472,7 @@ def main():
                          "hbm_frac": HBM_BYTES_PER_CALL / kernel_s / 8e12,
                          "traffic": PMC_TRAFFIC_BYTES,
                          "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes "
-                                         "(profiles/r1/pmc_matcher8k_u.txt); includes the 4 MB of "
+                                         "(profiles/r1/pmc_matcher8k_v.txt); includes the 4 MB of "
                                          "split results the kernel writes for the merge"},
         }
     # The secondary sections exchange records between ranks.  The primary measurement is
