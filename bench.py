@@ -372,9 +372,14 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # SLAMHIP_BENCH_FORCE_DIST=1: take the multi-rank code path (process group, barriers,
+    # all_reduce of the time, record gather) with a single rank as well, so that the
+    # RCCL calls of an N-GPU run can be exercised on a one-GPU box.
+    force_dist = os.environ.get("SLAMHIP_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -445,6 +450,7 @@ def main():
             "value": compares * args.steps * world / elapsed,
             "unit": "compares/s",
             "n_gpus": world,
+            "dist_backend": backend if dist is not None else None,
             "steps": args.steps,
             "warmup": args.warmup,
             "preheat_s": args.preheat,
@@ -479,11 +485,13 @@ def main():
     # complete at this point: if a section fails on one rank (the others would then wait in
     # a collective for ever) or does not finish in time, rank 0 still prints the line, with
     # what went wrong, and every rank ends.
+    # Exit code 3 = the primary line was printed but a secondary section hung or failed
+    # (a GPU hang or exception must not reach the launcher as success).
     def abandon():
         if rank == 0:
             line["secondary_sections"] = f"abandoned after {args.section_timeout} s"
             print(json.dumps(line), flush=True)
-        os._exit(0)
+        os._exit(3)
     watchdog = threading.Timer(args.section_timeout, abandon)
     watchdog.daemon = True
     watchdog.start()
@@ -526,8 +534,9 @@ def main():
                 line["parity_vs_cpu_port"] = bool((idx2.cpu().numpy() == ci).all() and
                                                   (dist2.cpu().numpy() == cd).all())
         print(json.dumps(line), flush=True)
-    if failed and world > 1:
-        os._exit(0)                          # the other ranks may be inside a collective
+    if failed:
+        sys.stdout.flush()
+        os._exit(3)                          # the other ranks may be inside a collective
     if dist is not None:
         dist.destroy_process_group()
 

@@ -15,8 +15,11 @@
  *    calls are asynchronous on that stream and return after enqueueing.
  *  - Return value: SLAMHIP_OK (0) or a negative SLAMHIP_E* code.  Nothing throws
  *    across this boundary.  slamhip_strerror() maps a code to text.
- *  - Thread-safety: no global mutable state; calls on different streams/devices
- *    may run concurrently.
+ *  - Thread-safety: the compute entry points keep no global mutable state;
+ *    calls on different streams/devices may run concurrently.  Exceptions: the
+ *    diagnostics entry points slamhip_tune() and slamhip_profile_begin()/_end()
+ *    set process-global, unsynchronised state and must not be called while
+ *    another thread is inside the library.
  *
  * Each entry point cites the reference interface (GuyShmueli/SLAM, paths
  * relative to the reference root) whose arithmetic it replaces.
@@ -31,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SLAMHIP_VERSION 100 /* 0.1.0 */
+#define SLAMHIP_VERSION 101 /* 0.1.1 */
 
 enum {
   SLAMHIP_OK = 0,
@@ -332,6 +335,10 @@ typedef struct slamhip_frontend_args {
                                             n_iter_required, math-domain flag, N, mask count, 0 */
   void *d_workspace;
   size_t workspace_bytes;
+  int64_t first_pair;        /* index of this batch's first pair in the caller's numbering of the
+                                whole sequence: the device sampler draws pair p's samples from
+                                (seed, first_pair + p), so a sequence cut into batches or shards
+                                gets the samples of the uncut run.  d_samples rows stay local. */
 } slamhip_frontend_args;
 
 size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *args);

@@ -55,9 +55,12 @@ SEED0 = 4100          # numpy.random.default_rng() call k inside the reference g
 
 
 class KP:
-    """What the reference reads of a cv2.KeyPoint: `.pt`."""
+    """What the reference reads of a cv2.KeyPoint: `.pt`.  OpenCV keeps the point as a
+    Point2f, so the coordinates come back rounded to float32 (and widened to Python
+    floats); that matters for LoopClosure.frame_data, which builds key points from
+    Link.y = (yL + yR) / 2, in general not a float32 value."""
     def __init__(self, x, y, size=1):
-        self.pt = (float(x), float(y))
+        self.pt = (float(np.float32(x)), float(np.float32(y)))
 
 
 class DM:

@@ -120,8 +120,10 @@ def consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loo
     cross_check = LoopClosure's frame_cross_check (the matcher of :192)."""
     links_i, des_i = kf_cand
     links_n, des_n = kf_curr
-    kpL_i, kpR_i = links_i[:, [0, 2]], links_i[:, [1, 2]]              # frame_data, :152-164
-    kpL_n, kpR_n = links_n[:, [0, 2]], links_n[:, [1, 2]]
+    # frame_data, :152-164: cv2.KeyPoint(x, y, 1) keeps float32 coordinates
+    f32 = lambda a: np.asarray(a, np.float64).astype(np.float32).astype(np.float64)
+    kpL_i, kpR_i = f32(links_i[:, [0, 2]]), f32(links_i[:, [1, 2]])
+    kpL_n, kpR_n = f32(links_n[:, [0, 2]]), f32(links_n[:, [1, 2]])
     obj = so.triangulate_cv(cam.P_left, cam.P_right, kpL_i, kpR_i, out_fp64=True)   # :179-180
     qi, ti, di = _bf_match(des_i, des_n, knn2, cross_check)             # :192-195
     out = {"query_idx": qi, "train_idx": ti, "dist": di, "obj": obj, "ok": False, "Rt": None,

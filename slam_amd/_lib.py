@@ -94,6 +94,7 @@ class FrontendArgs(C.Structure):
         ("d_tm_query", _vp), ("d_tm_train", _vp), ("d_tm_dist", _vp), ("d_tm_mask", _vp),
         ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_ransac_info", _vp),
         ("d_workspace", _vp), ("workspace_bytes", _sz),
+        ("first_pair", C.c_int64),
     ]
 
 

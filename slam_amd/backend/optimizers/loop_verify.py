@@ -110,9 +110,14 @@ class PairVerifier:
         off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
         links = np.concatenate([np.asarray(k[0], dtype=np.float64).reshape(-1, 3) for k in keyframes])
         des = np.concatenate([np.asarray(k[1], dtype=np.uint8) for k in keyframes])
-        kp_l = np.ascontiguousarray(links[:, [0, 2]])
-        kp_r = np.ascontiguousarray(links[:, [1, 2]])
-        self._kf_host = (kp_l.astype(np.float32), off)      # left pixels as cv2.KeyPoint keeps them
+        # LoopClosure.frame_data rebuilds the keypoints as cv2.KeyPoint(x, y, 1)
+        # (loop_closure.py:152-164), which stores float32: the fp64 triangulation sees the
+        # link coordinates rounded to float32, and Link.y = (yL + yR) / 2 is in general
+        # not a float32 value.
+        kp_l32 = np.ascontiguousarray(links[:, [0, 2]]).astype(np.float32)
+        kp_r32 = np.ascontiguousarray(links[:, [1, 2]]).astype(np.float32)
+        kp_l, kp_r = kp_l32.astype(np.float64), kp_r32.astype(np.float64)
+        self._kf_host = (kp_l32, off)      # left pixels as cv2.KeyPoint keeps them
         self._kf = {"n": np.asarray(n, dtype=np.int64), "off": off,
                     "kp_l": kernels.to_device(kp_l, torch.float64),
                     "kp_r": kernels.to_device(kp_r, torch.float64),

@@ -186,7 +186,11 @@ class TrackingFrontend:
         return inputs
 
     # ---------------------------------------------------------------------- run
-    def run(self, frames_or_inputs, samples: Optional[np.ndarray] = None) -> FrontendResult:
+    def run(self, frames_or_inputs, samples: Optional[np.ndarray] = None,
+            first_pair: int = 0) -> FrontendResult:
+        """`first_pair`: index of this batch's first pair in the whole sequence; the
+        device sampler keys pair p's samples by (seed, first_pair + p), so batches and
+        shards of a sequence draw the samples of the uncut run."""
         inp = frames_or_inputs if isinstance(frames_or_inputs, FrontendInputs) else self.upload(frames_or_inputs)
         F = inp.n_frames
         NL, NR = int(inp.off_left[-1]), int(inp.off_right[-1])
@@ -230,6 +234,7 @@ class TrackingFrontend:
         a.pixel_thresh, a.disparity_min = self.pixel_thresh, self.disparity_min
         a.ransac_thresh, a.p_success = self.pixel_thresh, self.p_success
         a.n_iter_max, a.refine_iters, a.seed = self.n_iter_max, self.refine_iters, self.seed
+        a.first_pair = int(first_pair)
         a.stereo_cross_check, a.temporal_cross_check = int(self.stereo_cross_check), int(self.frame_cross_check)
         d_samples = None
         if samples is not None:

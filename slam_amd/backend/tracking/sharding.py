@@ -295,19 +295,22 @@ def gather_records(blob: torch.Tensor, dst: int = 0, group=None) -> Optional[Lis
 
 
 def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
-                samples: Optional[np.ndarray] = None, dst: int = 0) -> Optional[SequenceResult]:
+                samples: Optional[np.ndarray] = None, dst: int = 0,
+                force_collective: bool = False) -> Optional[SequenceResult]:
     """Process this rank's share of `frames` on its GPU and gather the records
-    on rank `dst`, which returns the merged result (other ranks return None)."""
+    on rank `dst`, which returns the merged result (other ranks return None).
+    With one rank the record is parsed directly; `force_collective` sends it
+    through the gather all the same (needs an initialised process group)."""
     n_frames = len(frames)
     lo, hi, (plo, phi), (flo, fhi) = frames_for_rank(n_frames, world, rank)
     desc_bytes = int(np.asarray(frames[0][2]).shape[1])
     if hi > lo:
         s = None if samples is None else samples[plo:phi]
-        res = frontend.run(list(frames[lo:hi]), samples=s)
+        res = frontend.run(list(frames[lo:hi]), samples=s, first_pair=plo)
         blob = pack_result(res, (flo - lo, fhi - lo), (plo - lo, phi - lo), flo, plo)
     else:
         blob = torch.from_numpy(pack_records([], [], 0, 0, desc_bytes))
-    if world == 1:
+    if world == 1 and not force_collective:
         merged = merge_records([blob.cpu().numpy()], n_frames)
     else:
         got = gather_records(blob, dst, group)

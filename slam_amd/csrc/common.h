@@ -35,8 +35,14 @@ extern int g_ransac_screen;
 // pairs), 1 = always rounds of 256 hypotheses.  Set through slamhip_tune(4, value).
 extern int g_ransac_mode;
 
+// splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
-                            int desc_bytes, long long n_out = -1, bool prepacked = false);
+                            int desc_bytes, long long n_out = -1, bool prepacked = false,
+                            int splits = 0);
+// Number of train splits the matcher chooses for a launch of n_pairs pairs of at most
+// max_nq x max_nt rows.  A caller that runs several launches through one workspace
+// passes the value of its largest launch to every one of them.
+int knn2_plan_splits(int n_pairs, int max_nq, int max_nt, int desc_bytes);
 // Batched top-2 matcher.  prepacked: rows are already W-dword packed (row_stride
 // = 4*W, 16-byte aligned).  Pair p owns query rows [q_off[p], q_off[p] + count)
 // with count = q_cnt[p] (or q_off[p+1]-q_off[p] when q_cnt is NULL); same for t.
@@ -48,7 +54,8 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
          hipStream_t st, const int32_t *d_out_off = nullptr, int n_out_total = -1,
-         bool best_only = false);   // best_only: second-best entries come back as -1
+         bool best_only = false,    // best_only: second-best entries come back as -1
+         int splits = 0);
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,

@@ -619,7 +619,8 @@ int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
 int g_force_sort = 0;      // 0 auto, 1 rank counting, 2 bitonic network (where it fits)
 
 MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
-                    int desc_bytes, long long n_out = -1, bool prepacked = false) {
+                    int desc_bytes, long long n_out = -1, bool prepacked = false,
+                    int pinned_splits = 0) {
   if (n_out < 0) n_out = nq_total;
   MatchPlan p;
   p.W = slamhip_packed_words(desc_bytes);
@@ -656,6 +657,7 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   if (s > by_rows) s = by_rows;
   if (s > kMaxSplits) s = kMaxSplits;
   if (s < 1) s = 1;
+  if (pinned_splits > 0) s = pinned_splits > kMaxSplits ? kMaxSplits : pinned_splits;
   if (g_force_splits > 0) s = g_force_splits > kMaxSplits ? kMaxSplits : g_force_splits;
   p.splits = (int)s;
   size_t o = 0;
@@ -684,7 +686,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
              void *d_workspace, size_t workspace_bytes, void *stream, bool prepacked = false,
              const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr,
              uint8_t *d_keep = nullptr, double ratio = 0.0, const int32_t *d_out_off = nullptr,
-             int n_out_total = -1, bool best_only = false) {
+             int n_out_total = -1, bool best_only = false, int pinned_splits = 0) {
   if (n_out_total < 0) n_out_total = nq_total;
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
     return SLAMHIP_EINVAL;
@@ -698,7 +700,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   if (n_pairs > 1 && (!d_q_off || !d_t_off)) return SLAMHIP_EINVAL;
   if (max_nq == 0) return SLAMHIP_OK;
   const MatchPlan p =
-      make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out_total, prepacked);
+      make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out_total, prepacked,
+                pinned_splits);
   if (!d_workspace || workspace_bytes < p.total) return SLAMHIP_EWORKSPACE;
   hipStream_t st = (hipStream_t)stream;
 
@@ -940,18 +943,22 @@ int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total
 namespace slamhip_internal {
 
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
-                            int desc_bytes, long long n_out, bool prepacked) {
-  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out, prepacked).total;
+                            int desc_bytes, long long n_out, bool prepacked, int splits) {
+  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out, prepacked, splits).total;
+}
+
+int knn2_plan_splits(int n_pairs, int max_nq, int max_nt, int desc_bytes) {
+  return make_plan(0, 0, n_pairs, max_nq, max_nt, desc_bytes, 0, true).splits;
 }
 
 int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total, int desc_bytes,
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
-         hipStream_t st, const int32_t *d_out_off, int n_out_total, bool best_only) {
+         hipStream_t st, const int32_t *d_out_off, int n_out_total, bool best_only, int splits) {
   return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
                   n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, (void *)st,
-                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total, best_only);
+                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total, best_only, splits);
 }
 
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,

@@ -329,7 +329,8 @@ struct RansacParams {
   int n_iter_max;
   int min_points;  // pairs with fewer correspondences are not attempted
   unsigned long long seed;
-  long long pair0;  // index of the launch's first pair in the caller's numbering (sampling)
+  long long pair0;  // index of the launch's first pair among the pairs of this call (sample table row)
+  long long seq0;   // index of this call's first pair in the caller's numbering of the whole job (sampler)
 };
 
 // grid (pairs, slots).  A launch covers `slots` consecutive blocks of kHypPerRound
@@ -395,7 +396,10 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
       const int32_t *sp = samples + ((size_t)gp * prm.n_iter_max + it) * 4;
       for (int k = 0; k < 4; ++k) s4[k] = min(max(sp[k], 0), n - 1);
     } else {
-      unsigned long long r = splitmix64(prm.seed ^ (gp << 32) ^ (unsigned long long)it);
+      // keyed by the pair's index in the whole job, so that batching, chunking and
+      // sharding over ranks do not change a pair's samples
+      const unsigned long long sp_ = (unsigned long long)(prm.seq0 + prm.pair0 + p);
+      unsigned long long r = splitmix64(prm.seed ^ (sp_ << 32) ^ (unsigned long long)it);
       for (int k = 0; k < 4; ++k) {
         int c = 0;
         for (int tries = 0; tries < 64; ++tries) {
@@ -835,6 +839,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   prm.min_points = 4;
   prm.seed = a->seed;
   prm.pair0 = 0;
+  prm.seq0 = a->first_pair;
   rc = run_pair_ransac(a->d_off_left, tcount, cx, cpl, cpr, a->d_samples, prm, F - 1, a->max_left,
                        a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st);
   if (rc) return rc;
@@ -847,14 +852,30 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
 // ---------------------------------------------------------------------------
 // Pair verification (loop-closure candidates).
 // ---------------------------------------------------------------------------
+constexpr int kVerifyChunk = 32768;   // pairs per group of launches (grid z limit is 65535)
+
+// The pair list runs in chunks of kVerifyChunk pairs plus a shorter last chunk.  Left to
+// itself the matcher would pick more train splits for a launch with fewer pairs, and
+// its partial buffer (splits x output rows) would outgrow a workspace sized for the
+// full chunk; every chunk of a call therefore runs with the split count of the
+// largest one.
+static int verify_chunk(const slamhip_verify_args *a) {
+  return a->n_pairs < kVerifyChunk ? (a->n_pairs > 0 ? a->n_pairs : 1) : kVerifyChunk;
+}
+static int verify_splits(const slamhip_verify_args *a, bool swapped) {
+  return slamhip_internal::knn2_plan_splits(verify_chunk(a), swapped ? a->max_t : a->max_q,
+                                            swapped ? a->max_q : a->max_t, a->desc_bytes);
+}
 // workspace of the matcher calls of a chunk of pairs (forward, and swapped when cross-checking)
-static size_t verify_knn_bytes(const slamhip_verify_args *a, int chunk) {
+static size_t verify_knn_bytes(const slamhip_verify_args *a) {
+  const int chunk = verify_chunk(a);
   size_t k = slamhip_internal::knn2_workspace_bytes(a->n_rows_total, a->n_rows_total, chunk, a->max_q,
-                                                    a->max_t, a->desc_bytes, (long long)a->n_out_total, true);
+                                                    a->max_t, a->desc_bytes, (long long)a->n_out_total, true,
+                                                    verify_splits(a, false));
   if (a->cross_check) {
     const size_t k2 = slamhip_internal::knn2_workspace_bytes(
         a->n_rows_total, a->n_rows_total, chunk, a->max_t, a->max_q, a->desc_bytes,
-        (long long)(a->n_tout_total > 0 ? a->n_tout_total : 0), true);
+        (long long)(a->n_tout_total > 0 ? a->n_tout_total : 0), true, verify_splits(a, true));
     if (k2 > k) k = k2;
   }
   return k;
@@ -866,7 +887,7 @@ size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
     return 0;
   const int W = slamhip_packed_words(a->desc_bytes);
   const size_t N = (size_t)a->n_rows_total, O = (size_t)a->n_out_total;
-  const int chunk = a->n_pairs < 32768 ? (a->n_pairs > 0 ? a->n_pairs : 1) : 32768;
+  const int chunk = verify_chunk(a);
   size_t o = 0;
   auto take = [&](size_t bytes) { o = slamhip_align_up(o + bytes, 256); };
   take(N * W * 4);            // packed descriptors
@@ -874,7 +895,7 @@ size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
   take(O * 4);                // order
   take(O * 12); take(O * 8); take(O * 8);  // cx, cpl, cpr
   take((size_t)(a->n_pairs > 0 ? a->n_pairs : 1) * 4);  // counts
-  take(verify_knn_bytes(a, chunk));
+  take(verify_knn_bytes(a));
   take(ransac_workspace_bytes(chunk, a->n_iter_max));
   if (a->cross_check) {
     const size_t TO = (size_t)(a->n_tout_total > 0 ? a->n_tout_total : 0);
@@ -906,8 +927,9 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
   int32_t *order = (int32_t *)take(O * 4);
   float *cx = (float *)take(O * 12), *cpl = (float *)take(O * 8), *cpr = (float *)take(O * 8);
   int32_t *tcount = (int32_t *)take((size_t)(a->n_pairs > 0 ? a->n_pairs : 1) * 4);
-  const int chunk_max = a->n_pairs < 32768 ? (a->n_pairs > 0 ? a->n_pairs : 1) : 32768;
-  const size_t knn_bytes = verify_knn_bytes(a, chunk_max);
+  const int chunk_max = verify_chunk(a);
+  const size_t knn_bytes = verify_knn_bytes(a);
+  const int splits_fwd = verify_splits(a, false), splits_swp = verify_splits(a, true);
   void *knn_ws = (void *)take(knn_bytes);
   void *ransac_ws = (void *)take(ransac_workspace_bytes(chunk_max, a->n_iter_max));
   int32_t *ridx2 = nullptr, *rdist2 = nullptr;
@@ -953,7 +975,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
       rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
                                   a->n_rows_total, a->desc_bytes, W * 4, true, qb, qc, tb, tc, np,
                                   a->max_q, a->max_t, idx2, dist2, knn_ws, knn_bytes, st, ob,
-                                  a->n_out_total, true);
+                                  a->n_out_total, true, splits_fwd);
       if (rc) return rc;
     } else {
       // the rows of the current keyframe choose among the candidate's, then bid for them
@@ -964,7 +986,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
         rc = slamhip_internal::knn2((const uint8_t *)packed, a->n_rows_total, (const uint8_t *)packed,
                                     a->n_rows_total, a->desc_bytes, W * 4, true, tb, tc, qb, qc, np,
                                     a->max_t, a->max_q, ridx2, rdist2, knn_ws, knn_bytes, st, tob,
-                                    a->n_tout_total, true);
+                                    a->n_tout_total, true, splits_swp);
         if (rc) return rc;
         hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_t, kBlock), np), dim3(kBlock), 0,
                            st, tob, tc, ob, ridx2, rdist2, bid);
@@ -980,8 +1002,9 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
                        (const float *)a->d_xyz, a->d_kp_left, a->d_kp_right, a->d_tm_query,
                        a->d_tm_train, a->d_tm_dist, tcount + c0, cx, cpl, cpr);
     SLAMHIP_CHECK_LAUNCH();
-    prm.seed = a->seed + (unsigned long long)c0 * 0x9E3779B97F4A7C15ull;
+    prm.seed = a->seed;
     prm.pair0 = 0;
+    prm.seq0 = c0;
     rc = run_pair_ransac(ob, tcount + c0, cx, cpl, cpr, nullptr, prm, np, a->max_q,
                          a->d_pose_ransac + 12 * (size_t)c0, a->d_tm_mask,
                          a->d_info + 8 * (size_t)c0, ransac_ws, st);

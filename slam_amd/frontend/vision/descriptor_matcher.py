@@ -17,6 +17,12 @@ from ... import kernels
 from ...types import DMatch, MatchList
 
 
+class KnnMatches(list):
+    """knn_match result: the list cv2.BFMatcher.knnMatch returns, plus the norm the
+    distances were computed under ("hamming" or "l2"), which ratio_test reads."""
+    norm = None
+
+
 class DescriptorMatcher:
     def __init__(self, cross_check, matcher_type="bf", superglue_cfg=None):
         self.matcher_type = matcher_type.lower()
@@ -83,7 +89,8 @@ class DescriptorMatcher:
             raise ValueError("cross_check requires k == 1")  # cv2 asserts the same
         idx2, dist2 = self.knn_arrays(desL, desR)
         idx2, dist2 = idx2.cpu().numpy(), dist2.cpu().numpy()
-        out = []
+        out = KnnMatches()
+        out.norm = "hamming" if self._is_binary(desL) else "l2"
         for i in range(idx2.shape[0]):
             out.append(tuple(DMatch(i, idx2[i, j], 0, dist2[i, j])
                              for j in range(k) if idx2[i, j] >= 0))
@@ -101,9 +108,12 @@ class DescriptorMatcher:
         for i, pair in enumerate(raw):
             for j, m in enumerate(pair[:2]):
                 d[i, j] = float(m.distance)
-        if np.all(d == np.round(d)):       # Hamming distances: the device kernel
+        if getattr(raw, "norm", None) == "hamming":     # integer distances: the int32 kernel
             keep = kernels.ratio_test(d.astype(np.int32), ratio).cpu().numpy()
-        else:                              # L2 distances (float32)
+        else:
+            # float32 distances (L2), or a plain list whose norm is not recorded: the
+            # float kernel widens to fp64 before comparing, so Hamming distances (exact
+            # in float32) get the same decisions from it as from the int32 kernel
             keep = kernels.ratio_test_f32(d.astype(np.float32), ratio).cpu().numpy()
         for i, pair in enumerate(raw):
             if len(pair) == 0:

@@ -71,8 +71,9 @@ def hamming_knn2(q, t, out=None) -> Tuple[torch.Tensor, torch.Tensor]:
     if out is not None:
         idx2, dist2 = out
         if idx2.shape != (nq, 2) or dist2.shape != (nq, 2) or idx2.dtype != torch.int32 \
-                or dist2.dtype != torch.int32 or not idx2.is_contiguous() or not dist2.is_contiguous():
-            raise ValueError("out must be two contiguous (nq,2) int32 device tensors")
+                or dist2.dtype != torch.int32 or not idx2.is_contiguous() or not dist2.is_contiguous() \
+                or idx2.device != q.device or dist2.device != q.device:
+            raise ValueError("out must be two contiguous (nq,2) int32 tensors on the descriptors' device")
     else:
         idx2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
         dist2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
@@ -96,6 +97,11 @@ def hamming_knn2_ratio(q, t, ratio: float, out=None):
     d = q.shape[1] if nq else (t.shape[1] if nt else 1)
     if out is not None:
         idx2, dist2, keep = out
+        for o, shape, dt in ((idx2, (nq, 2), torch.int32), (dist2, (nq, 2), torch.int32),
+                             (keep, (nq,), torch.uint8)):
+            if tuple(o.shape) != shape or o.dtype != dt or not o.is_contiguous() or o.device != q.device:
+                raise ValueError("out must be contiguous device tensors on the descriptors' device: "
+                                 "(nq,2) int32, (nq,2) int32, (nq,) uint8")
     else:
         idx2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)
         dist2 = torch.empty((nq, 2), dtype=torch.int32, device=q.device)

@@ -226,3 +226,70 @@ def test_verify_pairs_with_cross_checked_matcher():
     assert (res["n_matches"] < plain["n_matches"]).any() and 2 <= n_ok < len(pairs)
     vm = res.verified_matches()
     assert vm["off"][-1] == res["n_matches"][res["ok"]].sum() == len(vm["mask"])
+
+
+def test_pair_list_longer_than_one_chunk_with_a_short_tail():
+    """More than 32768 pairs run as a full chunk plus a short one through the same
+    workspace; the short chunk must not outgrow it (it runs with the full chunk's
+    split count) and must give the same matches as the same pairs in the full chunk."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=4, n_features=900, seed=8, clutter=0.3)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(4))]
+    st = TrackingFrontend(cam, n_iter_max=1).run(frames)
+    kfs = [(st.frame(k)["links"], st.frame(k)["inlier_des_left"]) for k in range(4)]
+    assert min(len(k[0]) for k in kfs) > 300
+    base = np.array([(i, n) for n in range(4) for i in range(n)], dtype=np.int64)       # 6 pairs
+    n_pairs = 32768 + 100
+    pairs = base[np.arange(n_pairs) % len(base)]
+    ver = PairVerifier(cam, n_iter_max=256, seed=2).set_keyframes(kfs)
+    res = ver.verify(pairs)
+    assert (res["n_matches"] == np.array([len(kfs[i][0]) for i in pairs[:, 0]])).all()
+    tail = np.arange(32768, n_pairs)
+    for p in tail[:: 7]:
+        twin = int(p % len(base))                 # the same keyframe pair inside the first chunk
+        a, b = res.pair_matches(int(p)), res.pair_matches(twin)
+        for key in ("query_idx", "train_idx", "dist"):
+            np.testing.assert_array_equal(a[key], b[key])
+        assert a["mask"].sum() == res["n_inliers"][p]
+    # consecutive frames verify in the tail as they do in the first chunk
+    # (every copy of a pair draws its own samples, so a borderline pair may differ between copies)
+    kind = np.arange(n_pairs) % len(base)
+    sure = [k for k in range(len(base)) if res["ok"][:32768][kind[:32768] == k].mean() > 0.999]
+    assert sure, "no keyframe pair verifies reliably"
+    assert all(res["ok"][32768:][kind[32768:] == k].all() for k in sure)
+
+
+def test_keyframe_points_use_float32_keypoints_like_cv2_keypoint(golden):
+    """LoopClosure.frame_data builds cv2.KeyPoint(x, y, 1) from the stored links, so the
+    fp64 triangulation sees Link.y = (yL + yR) / 2 rounded to float32.  The reference's own
+    run holds the resulting float32 points of the consensus set (refine_obj): the device's
+    points of the same features are the same float32 values."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    g = golden("ref_consensus_flow.npz")
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    ids = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("links_"))
+    keyframes = [(g[f"links_{k}"], g[f"des_{k}"]) for k in ids]
+    off = np.concatenate([[0], np.cumsum([len(k[0]) for k in keyframes])])
+    y = np.concatenate([k[0][:, 2] for k in keyframes])
+    assert (y.astype(np.float32).astype(np.float64) != y).mean() > 0.2     # the rounding matters here
+    checked = 0
+    for i, (curr, cand, gate, cc) in enumerate(g["cases"]):
+        if not bool(g[f"ok_{i}"]):
+            continue
+        ver = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i,
+                           frame_cross_check=bool(cc)).set_keyframes(keyframes)
+        c = ids.index(int(cand))
+        res = ver.verify(np.array([[c, ids.index(int(curr))]], dtype=np.int64))
+        m = res.pair_matches(0)
+        ref_mask = g[f"mask_{i}"]
+        got = res["xyz"][off[c]:off[c + 1]][m["query_idx"]][ref_mask]
+        ref = g[f"refine_obj_{i}"]
+        assert got.shape == ref.shape and got.dtype == np.float32 and ref.dtype == np.float32
+        assert (got == ref).mean() > 0.99 and np.abs(got - ref).max() <= 2.5e-7 * np.abs(ref).max()
+        checked += 1
+    assert checked >= 2

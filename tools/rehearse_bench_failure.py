@@ -2,7 +2,8 @@
 (run under torch.distributed.run like bench.py, same arguments):
     SLAMHIP_REHEARSE_FAIL_RANK=1  -> bench_frontend raises on that rank
     SLAMHIP_REHEARSE_HANG_RANK=1  -> bench_frontend never returns on that rank
-Rank 0 must still print the primary JSON line and every rank must end."""
+Rank 0 must still print the primary JSON line and every rank must end, with exit
+code 3 (tests/test_gpu_rccl.py asserts it for the one-rank case)."""
 import os
 import sys
 import time
