@@ -102,6 +102,25 @@ int slamhip_hamming_knn2_ratio(const uint8_t *d_query, int nq, const uint8_t *d_
                                int32_t *d_dist2, uint8_t *d_keep, void *d_workspace,
                                size_t workspace_bytes, void *stream);
 
+/* The same call for callers that cannot allocate device memory or carry a
+ * workspace: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference.  Same arguments
+ * and results as slamhip_hamming_knn2_ratio minus the workspace: the matcher's
+ * scratch is a file-scope device array of SLAMHIP_STATIC_SCRATCH_BYTES inside
+ * the library (one copy per GPU, held until the process ends), so the call
+ * allocates and frees nothing.  nq and nt may be at most
+ * SLAMHIP_STATIC_MAX_ROWS; larger calls return SLAMHIP_EUNSUPPORTED.  All
+ * calls on one GPU share that GPU's array: calls that overlap in time on one
+ * GPU (different streams or threads) race and must be serialised by the
+ * caller.  The first call on a device looks up the array's address
+ * (hipGetSymbolAddress); make that call outside stream capture. */
+#define SLAMHIP_STATIC_MAX_ROWS 8192
+#define SLAMHIP_STATIC_SCRATCH_BYTES (8u << 20)
+int slamhip_hamming_knn2_ratio_static(const uint8_t *d_query, int nq, const uint8_t *d_train,
+                                      int nt, int desc_bytes, int row_stride, double ratio,
+                                      int32_t *d_idx2, int32_t *d_dist2, uint8_t *d_keep,
+                                      void *stream);
+
 /* Batched form: n_pairs independent (query set, train set) problems in one
  * launch.  Pair p owns query rows [q_off[p], q_off[p+1]) and train rows
  * [t_off[p], t_off[p+1]) of the concatenated descriptor arrays; train indices

@@ -51,6 +51,8 @@ SIGNATURES = {
     "slamhip_hamming_knn2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "slamhip_hamming_knn2_ratio": (
         _i, [_vp, _i, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "slamhip_hamming_knn2_ratio_static": (
+        _i, [_vp, _i, _vp, _i, _i, _i, _d, _vp, _vp, _vp, _vp]),
     "slamhip_hamming_knn2_batched": (
         _i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     "slamhip_ratio_test": (_i, [_vp, _i, _d, _vp, _vp]),

@@ -19,6 +19,8 @@
 // distances, for the best and for the second best
 // (call site: frontend/vision/descriptor_matcher.py:33 of the reference).
 #include "common.h"
+#include <atomic>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -935,6 +937,64 @@ int slamhip_sort_by_distance(const int32_t *d_dist, int dist_stride, int n_total
               (hipStream_t)stream);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
+}
+
+// ---------------------------------------------------------------------------
+// The k=2 + ratio-test call for callers that cannot allocate: no workspace
+// argument, the matcher's scratch (packed rows, per-split partial results) lives
+// in a file-scope device array.  Every GPU the library runs on holds its own copy
+// of the array at its own address; the address is looked up once per device, with
+// that device current, and only that pointer is ever handed to kernels (the
+// array's name is a host-side stand-in, not a device address).
+// ---------------------------------------------------------------------------
+}  // extern "C"
+
+namespace {
+constexpr size_t kStaticScratchBytes = (size_t)SLAMHIP_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::atomic<void *> g_scratch_ptr[kMaxDevices];   // per device; nullptr until looked up
+std::mutex g_scratch_mutex;
+
+// Device address of this device's copy of `scratch` (nullptr on error).
+void *static_scratch_for_current_device() {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+  void *p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+  if (p != nullptr) return p;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+  if (p != nullptr) return p;
+  void *addr = nullptr;
+  if (hipGetSymbolAddress(&addr, HIP_SYMBOL(scratch)) != hipSuccess || addr == nullptr) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  g_scratch_ptr[dev].store(addr, std::memory_order_release);
+  return addr;
+}
+}  // namespace
+
+extern "C" {
+
+int slamhip_hamming_knn2_ratio_static(const uint8_t *d_query, int nq, const uint8_t *d_train, int nt,
+                                      int desc_bytes, int row_stride, double ratio, int32_t *d_idx2,
+                                      int32_t *d_dist2, uint8_t *d_keep, void *stream) {
+  SLAMHIP_BEGIN();
+  if (nq < 0 || nt < 0) return SLAMHIP_EINVAL;
+  if (!d_keep && nq > 0) return SLAMHIP_EINVAL;
+  if (nq > SLAMHIP_STATIC_MAX_ROWS || nt > SLAMHIP_STATIC_MAX_ROWS) return SLAMHIP_EUNSUPPORTED;
+  if (desc_bytes < 1 || desc_bytes > SLAMHIP_MAX_DESC_BYTES) return SLAMHIP_EINVAL;
+  // the plan of any call within the row limit fits the array (checked again inside run_knn2)
+  if (make_plan(nq, nt, 1, nq, nt, desc_bytes).total > kStaticScratchBytes) return SLAMHIP_EUNSUPPORTED;
+  void *ws = static_scratch_for_current_device();
+  if (ws == nullptr) return SLAMHIP_ELAUNCH;
+  // Nothing in the scratch has to start at zero: the packing kernel writes every packed
+  // row the matcher reads and the matcher writes every (split, row) entry the fold reads.
+  return run_knn2(d_query, nq, d_train, nt, desc_bytes, row_stride, nullptr, nullptr, 1, nq, nt,
+                  d_idx2, d_dist2, ws, kStaticScratchBytes, stream, false, nullptr, nullptr, d_keep,
+                  ratio);
 }
 
 }  // extern "C"
