@@ -6,6 +6,11 @@
 
 // hipGetLastError() is sticky per thread: an error left behind by unrelated HIP
 // calls of the host application would otherwise be reported as ours.
+// Kernel family the matcher uses when nothing is forced: 1 = matrix cores, 0 = popcount.
+#ifndef SLAMHIP_DEFAULT_MFMA
+#define SLAMHIP_DEFAULT_MFMA 0
+#endif
+
 #define SLAMHIP_BEGIN() ((void)hipGetLastError())
 
 #define SLAMHIP_CHECK_LAUNCH()                         \
@@ -56,6 +61,13 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          hipStream_t st, const int32_t *d_out_off = nullptr, int n_out_total = -1,
          bool best_only = false,    // best_only: second-best entries come back as -1
          int splits = 0);
+// Matrix-core matcher (hamming_mfma.hip): same arguments as the popcount kernel's launch.
+// W = packed dwords per row, G = groups of 32 queries per wave (1, 2, 4; 32-word rows: 1, 2).
+int mfma_max_split_rows(int W);    // train rows one block may scan (width of its row index)
+void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
+                         const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
+                         const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
+                         int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2);
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,

@@ -20,6 +20,7 @@
 // (call site: frontend/vision/descriptor_matcher.py:33 of the reference).
 #include "common.h"
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -602,6 +603,8 @@ constexpr int kRowsPerSplit = 384;   // train rows per block the plan aims at wh
 struct MatchPlan {
   int W, Q, qblocks, splits, threads;
   bool use_lds;
+  bool mfma;   // matrix-core kernel (hamming_mfma.hip); G = groups of 32 queries per wave
+  int G;
   size_t off_qp, off_tp, off_part, total;
 };
 
@@ -615,8 +618,24 @@ struct ProfEvents {
 };
 ProfEvents g_prof;
 
-int g_force_variant = -1;  // diagnostics: -1 auto, bit0 = LDS, bits 1.. = Q
+// diagnostics: -1 auto; 0..7 popcount kernel variants (bit0 = LDS, bits 1.. = Q);
+// 8 = matrix-core kernel, 9 / 10 / 12 = the same with 1 / 2 / 4 query groups per wave
+int g_force_variant = -1;
+
+// Kernel family when nothing is forced: the environment variable SLAMHIP_MATCHER
+// ("popcount" or "mfma") read once, else the library default.
+bool default_mfma() {
+  static const int v = [] {
+    const char *e = getenv("SLAMHIP_MATCHER");
+    if (e && e[0] == 'p') return 0;
+    if (e && e[0] == 'm') return 1;
+    return SLAMHIP_DEFAULT_MFMA;
+  }();
+  return v != 0;
+}
 int g_force_splits = 0;
+int g_mfma_target_blocks = 1024;   // matrix-core kernel: blocks a launch aims at (knob 6)
+int g_mfma_rows_per_split = 1024;  // and train rows per block it does not exceed when blocks abound (knob 7)
 int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
 int g_force_sort = 0;      // 0 auto, 1 rank counting, 2 bitonic network (where it fits)
 
@@ -631,10 +650,47 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   // latency, two queries per lane cost occupancy.
   p.use_lds = true;
   p.Q = 1;
-  if (g_force_variant >= 0) {
+  p.mfma = default_mfma();
+  p.G = 0;
+  if (g_force_variant >= 8) {
+    p.mfma = true;
+    p.G = g_force_variant - 8;
+  } else if (g_force_variant >= 0) {
+    p.mfma = false;
     p.use_lds = (g_force_variant & 1) != 0;
     p.Q = (g_force_variant >> 1) == 2 && p.W <= 16 ? 2 : 1;
   }
+  // the matrix-core kernel indexes train rows inside a split with SH bits
+  const int mfma_rows = slamhip_internal::mfma_max_split_rows(p.W);
+  if (p.mfma && (long long)max_nt > (long long)kMaxSplits * mfma_rows) p.mfma = false;
+  if (p.mfma) {
+    // 4 waves x G groups of 32 queries per block; two groups unless one fills the last
+    // block of a pair much better, or the registers do not allow more (32-word rows)
+    int G = p.G;
+    if (G != 1 && G != 2 && G != 4) {
+      G = 2;
+      const int idle2 = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 256) * 256 - max_nq;
+      const int idle1 = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128) * 128 - max_nq;
+      if (idle2 - idle1 >= 128 && idle2 * 8 > max_nq) G = 1;
+    }
+    if (p.W == 32 && G > 2) G = 2;
+    p.G = G;
+    p.threads = kThreads;
+    p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128 * G);
+    const long long base_blocks = (long long)p.qblocks * (n_pairs > 0 ? n_pairs : 1);
+    long long s = (g_mfma_target_blocks + base_blocks - 1) / base_blocks;
+    const long long by_grain = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, g_mfma_rows_per_split);
+    if (s < by_grain) s = by_grain;
+    const int by_rows = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, 64);
+    if (s > by_rows) s = by_rows;
+    if (pinned_splits > 0) s = pinned_splits;
+    if (g_force_splits > 0) s = g_force_splits;
+    const long long need = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, mfma_rows);
+    if (s < need) s = need;
+    if (s > kMaxSplits) s = kMaxSplits;
+    if (s < 1) s = 1;
+    p.splits = (int)s;
+  } else {
   // Half-size blocks when that fills the last block of a pair much better (e.g. 610
   // queries: 3 x 256 leaves 158 lanes idle, 5 x 128 leaves 30).  Default variant only.
   p.threads = kThreads;
@@ -662,6 +718,7 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   if (pinned_splits > 0) s = pinned_splits > kMaxSplits ? kMaxSplits : pinned_splits;
   if (g_force_splits > 0) s = g_force_splits > kMaxSplits ? kMaxSplits : g_force_splits;
   p.splits = (int)s;
+  }
   size_t o = 0;
   p.off_qp = o;
   if (!prepacked) o = slamhip_align_up(o + (size_t)nq_total * p.W * 4, 256);
@@ -744,7 +801,10 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 #define SLAMHIP_DISPATCH_BEST(WW, TT)                                                              \
   launch_top2<WW, 1, true, TT, true>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, d_out_off, \
                                      nqs, nts, n_out_total, part, d_idx2, d_dist2)
-  if (best_only && p.use_lds && p.Q == 1 && p.W <= 16) {
+  if (p.mfma) {
+    slamhip_internal::launch_hamming_mfma(p.W, p.G, best_only, grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off,
+                                          d_t_cnt, d_out_off, nqs, nts, n_out_total, part, d_idx2, d_dist2);
+  } else if (best_only && p.use_lds && p.Q == 1 && p.W <= 16) {
     if (p.threads == kThreads / 2) { if (p.W == 8) SLAMHIP_DISPATCH_BEST(8, kThreads / 2); else SLAMHIP_DISPATCH_BEST(16, kThreads / 2); }
     else                           { if (p.W == 8) SLAMHIP_DISPATCH_BEST(8, kThreads); else SLAMHIP_DISPATCH_BEST(16, kThreads); }
   } else if (p.threads == kThreads / 2) {
@@ -823,6 +883,8 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 3) g_force_threads = value;
   else if (knob == 4) slamhip_internal::g_ransac_mode = value;
   else if (knob == 5) g_force_sort = value;
+  else if (knob == 6) g_mfma_target_blocks = value > 0 ? value : 1024;
+  else if (knob == 7) g_mfma_rows_per_split = value > 0 ? value : 1024;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
 }

@@ -1,0 +1,289 @@
+// Hamming top-2 matcher on the matrix cores of gfx950 (MI355X).
+//
+// Over D = 32 W bits (rows are zero padded to W dwords, padding bits are equal on
+// both sides), with every bit written as the FP4 value +1 (bit 0) or -1 (bit 1):
+//     <q', t'> = D - 2 * hamming(q, t)
+// so a 32 x 32 tile of distances is a 32 x 32 x D contraction, which
+// v_mfma_scale_f32_32x32x64_f8f6f4 does 64 bit pairs per instruction.  The
+// accumulator is preloaded and the train operand scaled (E8M0 block scale, a power
+// of two, exact) so that the instruction's result IS the matcher's sort key:
+//     C_in  = 2^(SH-1) * D + (MASK - local_row),      scale = 2^(SH-1)
+//     D_out = C_in + 2^(SH-1) * (D - 2 d) = (D - d) << SH | (MASK - local_row)
+// an integer below 2^24, exact in float32.  Larger key = smaller distance, then lower
+// train row: the order of a sequential scan with strict `<` insertion
+// (cv2.BFMatcher / batchDistance, the tie rule behind
+// frontend/vision/descriptor_matcher.py:33 of the reference).  What is left for
+// the vector ALU per (query, train row) is the running top-2 update: v_med3 + v_max.
+//
+// Work decomposition
+//   block  = 256 threads = 4 waves; wave = G groups of 32 queries whose expanded
+//            rows stay in registers (B operand) for the whole scan
+//   grid   = (query blocks, train splits, pairs), as the popcount kernel
+//   stage  = R train rows: loaded as packed dwords (coalesced 16-byte loads), expanded
+//            to FP4 on the fly (one dword -> four dwords: bit plane p of the dword,
+//            (x << (3 - p)) & 0x88888888 | 0x22222222), written to LDS in a
+//            16-byte-slot XOR swizzle that makes the A-fragment ds_read_b128 of 32
+//            rows conflict-free; double buffered, one barrier per stage.  A table of
+//            the stage's C_in values sits beside it (rows past the end hold a large
+//            negative number, so they can never win).
+//   tile   = 32 train rows x 32 queries: KS = W / 2 matrix instructions per group.
+// Accumulator layout (32 x 32): lane l holds query column l & 31 and train rows
+// (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0..15; lanes l and l ^ 32 meet at the end.
+// Both operands are fetched the same way (lane l: row l & 31, 16-byte chunk l >> 5 of the
+// k-step), so whatever order the instruction gives the 64 k positions is the same for A and B.
+#include "common.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+
+constexpr int kKeyShift = 21;
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+constexpr int kThreads = 256;
+
+template <int W> struct Geo {
+  static constexpr int KS = W / 2;                    // matrix instructions per 32 x 32 tile
+  static constexpr int CPR = W;                       // 16-byte chunks per expanded row
+  static constexpr int R = (W == 8) ? 128 : 64;       // train rows per stage
+  static constexpr int SH = (W == 32) ? 12 : 13;      // key = (D - d) << SH | (MASK - row)
+  static constexpr int MASK = (1 << SH) - 1;
+  static constexpr int UNITS = R * W / 4 / kThreads;  // 16-byte packed units per thread and stage
+  static_assert(R * W / 4 % kThreads == 0, "stage units divide over the block");
+};
+
+// Running top-2 of float keys (larger is better), invariant b1 >= b2 among valid keys.
+// Compiler builtins, not inline asm: the first read of a matrix-instruction result needs
+// wait states that the compiler only inserts for instructions it knows (with an asm
+// v_med3 as the first reader the second-best came out stale).
+__device__ __forceinline__ float fmed3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+// Larger of two keys through their bit patterns: valid keys are non-negative floats, whose
+// order is the order of their bits as integers, and every negative value ("no key", rows
+// past the end) stays below all of them either way; unlike fmaxf this needs no
+// canonicalising instruction in front.
+__device__ __forceinline__ float kmax(float a, float b) {
+  return __int_as_float(max(__float_as_int(a), __float_as_int(b)));
+}
+
+// one packed dword -> 32 FP4 values (16 bytes): nibble j of word p = bit 4 j + p
+__device__ __forceinline__ v4i expand_dword(uint32_t x) {
+  v4i o;
+  o[0] = (int)(((x << 3) & 0x88888888u) | 0x22222222u);
+  o[1] = (int)(((x << 2) & 0x88888888u) | 0x22222222u);
+  o[2] = (int)(((x << 1) & 0x88888888u) | 0x22222222u);
+  o[3] = (int)((x & 0x88888888u) | 0x22222222u);
+  return o;
+}
+
+// swizzle term of a row (XORed into the 16-byte chunk index)
+template <int W> __device__ __forceinline__ int row_swizzle(int row) {
+  return W == 8 ? ((row >> 1) & 7) : (row & 15);
+}
+
+template <int W, int G, bool BEST>
+__global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
+    const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
+    const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
+    const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
+    const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
+    uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2) {
+  using GEO = Geo<W>;
+  constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
+  constexpr int D = 32 * W;
+  constexpr int kStageSlots = R * CPR;                 // 16-byte slots per stage buffer
+  // one LDS object: two stage buffers, then two C_in tables of R floats
+  __shared__ uint4 lds[2 * kStageSlots + 2 * R / 4];
+  float *ctab = reinterpret_cast<float *>(lds + 2 * kStageSlots);
+
+  const int pair = blockIdx.z;
+  int q0 = 0, nq = nq_single, t0 = 0, nt = nt_single;
+  if (q_off != nullptr) {
+    q0 = q_off[pair];
+    nq = q_cnt ? q_cnt[pair] : q_off[pair + 1] - q0;
+    t0 = t_off[pair];
+    nt = t_cnt ? t_cnt[pair] : t_off[pair + 1] - t0;
+  }
+  const int o0 = out_off ? out_off[pair] : q0;
+  const int qblk = blockIdx.x * (4 * 32 * G);
+  if (qblk >= nq) return;  // block-uniform
+
+  const int n_splits = gridDim.y;
+  const int split = blockIdx.y;
+  // whole tiles per split, so that a split starts on a packed row boundary the stage
+  // loads can take 16 bytes at a time from; the host keeps a split within MASK + 1 rows
+  int rps = (nt + n_splits - 1) / n_splits;
+  rps = (rps + 31) & ~31;
+  const int r_begin = min(nt, split * rps);
+  const int r_end = min(nt, r_begin + rps);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+
+  // ---- queries -> expanded B fragments in registers
+  v8i bq[G][KS];
+  int qrow[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    qrow[g] = qblk + (wave * G + g) * 32 + r;
+    const uint32_t *src = qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const v4i e = expand_dword(src[2 * s + h]);
+      bq[g][s] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+    }
+  }
+  const int scale_t = 127 + SH - 1, scale_q = 127;   // E8M0: 2^(SH-1) and 1
+
+  float b1[G], b2[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) b1[g] = b2[g] = -1.0f;             // negative: no key yet
+
+  // ---- per-lane LDS read offsets (bytes) of the A fragment of k-step s inside a tile
+  const int fr = row_swizzle<W>(r);
+  int aoff[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) aoff[s] = (r * CPR + ((2 * s + h) ^ fr)) * 16;
+
+  // ---- stage loader: thread handles UNITS packed 16-byte units (4 dwords of one row)
+  auto load_stage = [&](int stage_begin, uint4 (&u)[GEO::UNITS]) {
+#pragma unroll
+    for (int k = 0; k < GEO::UNITS; ++k) {
+      const int unit = tid + k * kThreads;
+      const int row = unit / (W / 4), c4 = unit % (W / 4);
+      const int grow = min(stage_begin + row, r_end - 1);       // rows past the end: re-read the last
+      u[k] = *reinterpret_cast<const uint4 *>(tp + (size_t)(t0 + grow) * W + 4 * c4);
+    }
+  };
+  auto store_stage = [&](int buf, int stage_begin, const uint4 (&u)[GEO::UNITS]) {
+    uint4 *dst = lds + buf * kStageSlots;
+#pragma unroll
+    for (int k = 0; k < GEO::UNITS; ++k) {
+      const int unit = tid + k * kThreads;
+      const int row = unit / (W / 4), c4 = unit % (W / 4);
+      const int f = row_swizzle<W>(row);
+      const uint32_t x[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const v4i e = expand_dword(x[j]);
+        dst[row * CPR + ((4 * c4 + j) ^ f)] = make_uint4((uint32_t)e[0], (uint32_t)e[1], (uint32_t)e[2], (uint32_t)e[3]);
+      }
+    }
+    if (tid < R) {
+      const int lrow = stage_begin - r_begin + tid;               // row index inside the split
+      ctab[buf * R + tid] = (stage_begin + tid < r_end)
+                                ? (float)((D << (SH - 1)) + (MASK - lrow)) : -1.0e30f;
+    }
+  };
+
+  if (r_begin < r_end) {
+    uint4 u[GEO::UNITS];
+    load_stage(r_begin, u);
+    store_stage(0, r_begin, u);
+    __syncthreads();
+    int buf = 0;
+    for (int sb = r_begin; sb < r_end; sb += R, buf ^= 1) {
+      const bool more = sb + R < r_end;                            // block-uniform
+      if (more) load_stage(sb + R, u);
+      const char *base = reinterpret_cast<const char *>(lds + buf * kStageSlots);
+      const float *ct = ctab + buf * R;
+      const int rows = min(R, r_end - sb);
+#pragma unroll
+      for (int tile = 0; tile < R / 32; ++tile) {
+        if (tile * 32 < rows) {                                    // wave-uniform
+          v16f cin;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float4 c = *reinterpret_cast<const float4 *>(ct + tile * 32 + 8 * j + 4 * h);
+            cin[4 * j + 0] = c.x; cin[4 * j + 1] = c.y; cin[4 * j + 2] = c.z; cin[4 * j + 3] = c.w;
+          }
+          v16f acc[G];
+#pragma unroll
+          for (int s = 0; s < KS; ++s) {
+            const v4i a4 = *reinterpret_cast<const v4i *>(base + tile * 32 * CPR * 16 + aoff[s]);
+            const v8i a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+              acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[g][s], s == 0 ? cin : acc[g], 4, 4, 0,
+                                                                      scale_t, 0, scale_q);
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const float key = acc[g][i];
+              if (!BEST) b2[g] = fmed3(b1[g], b2[g], key);
+              b1[g] = kmax(b1[g], key);
+            }
+          }
+        }
+      }
+      if (more) store_stage(buf ^ 1, sb + R, u);
+      __syncthreads();
+    }
+  }
+
+  // ---- the two half-waves of a query meet; lane h == 0 writes
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const float o1 = __shfl_xor(b1[g], 32, 64), o2 = __shfl_xor(b2[g], 32, 64);
+    float m1 = b1[g], m2 = b2[g];
+    if (!BEST) { m2 = fmed3(m1, m2, o1); }
+    m1 = kmax(m1, o1);
+    if (!BEST) { m2 = fmed3(m1, m2, o2); }     // o2 <= o1 <= m1: this keeps the larger of m2, o2
+    if (h != 0 || qrow[g] >= nq) continue;
+    // key -> (distance, global train row); negative = none
+    uint32_t k1 = kNoKey, k2 = kNoKey;
+    if (m1 >= 0.0f) {
+      const uint32_t v = (uint32_t)m1;
+      k1 = ((uint32_t)(D - (int)(v >> SH)) << kKeyShift) | (uint32_t)(r_begin + (MASK - (int)(v & MASK)));
+    }
+    if (!BEST && m2 >= 0.0f) {
+      const uint32_t v = (uint32_t)m2;
+      k2 = ((uint32_t)(D - (int)(v >> SH)) << kKeyShift) | (uint32_t)(r_begin + (MASK - (int)(v & MASK)));
+    }
+    const size_t row = (size_t)(o0 + qrow[g]);
+    if (n_splits == 1) {
+      const uint32_t im = (1u << kKeyShift) - 1u;
+      idx2[2 * row + 0] = k1 == kNoKey ? -1 : (int32_t)(k1 & im);
+      idx2[2 * row + 1] = k2 == kNoKey ? -1 : (int32_t)(k2 & im);
+      dist2[2 * row + 0] = k1 == kNoKey ? -1 : (int32_t)(k1 >> kKeyShift);
+      dist2[2 * row + 1] = k2 == kNoKey ? -1 : (int32_t)(k2 >> kKeyShift);
+    } else {
+      partial[(size_t)split * nq_total + row] = make_uint2(k1, k2);
+    }
+  }
+}
+
+template <int W, int G, bool BEST>
+void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, const int32_t *q_off,
+            const int32_t *q_cnt, const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off,
+            int nq, int nt, int nq_total, uint2 *part, int32_t *idx2, int32_t *dist2) {
+  hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST>), grid, dim3(kThreads), 0, st, qp, tp, q_off, q_cnt,
+                     t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2);
+}
+
+}  // namespace
+
+namespace slamhip_internal {
+
+int mfma_max_split_rows(int W) { return W == 32 ? (1 << 12) : (1 << 13); }
+
+void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
+                         const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
+                         const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
+                         int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2) {
+#define SLAMHIP_MFMA_CASE(WW, GG)                                                                    \
+  if (W == WW && G == GG) {                                                                          \
+    if (best) launch<WW, GG, true>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,    \
+                                   nq_total, (uint2 *)part, idx2, dist2);                            \
+    else launch<WW, GG, false>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,        \
+                               nq_total, (uint2 *)part, idx2, dist2);                                \
+    return;                                                                                          \
+  }
+  SLAMHIP_MFMA_CASE(8, 1) SLAMHIP_MFMA_CASE(8, 2) SLAMHIP_MFMA_CASE(8, 4)
+  SLAMHIP_MFMA_CASE(16, 1) SLAMHIP_MFMA_CASE(16, 2) SLAMHIP_MFMA_CASE(16, 4)
+  SLAMHIP_MFMA_CASE(32, 1) SLAMHIP_MFMA_CASE(32, 2)
+#undef SLAMHIP_MFMA_CASE
+}
+
+}  // namespace slamhip_internal

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Matcher kernel variants side by side in one process (interleaved rounds): whole call and
+the top-2 kernel alone (HIP events on the launch stream) for one n x n pair.
+    python tools/time_matcher_variants.py [n] [desc_bytes]
+Variants are values of tune knob 0: 1 = popcount (LDS tile, one query per lane),
+9 / 10 / 12 = matrix-core kernel with 1 / 2 / 4 query groups per wave."""
+import ctypes as C
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slam_amd import _lib, kernels          # noqa: E402
+from slam_amd.utils.synth import matcher_workload   # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+D = int(sys.argv[2]) if len(sys.argv) > 2 else 61
+qn, tn = matcher_workload(n, n, D, seed=3)
+q = kernels.to_device(qn, torch.uint8)
+t = kernels.to_device(tn, torch.uint8)
+out = (torch.empty((n, 2), dtype=torch.int32, device=q.device),
+       torch.empty((n, 2), dtype=torch.int32, device=q.device),
+       torch.empty(n, dtype=torch.uint8, device=q.device))
+tune = _lib.lib.slamhip_tune
+configs = [(1, 0)] + [(v, s) for v in (9, 10, 12) for s in (0, 4, 8, 16, 32, 64)]
+ref = None
+best = {}
+for rnd in range(3):
+    for v, s in configs:
+        tune(0, v); tune(1, s)
+        for _ in range(20):
+            kernels.hamming_knn2_ratio(q, t, 0.8, out=out)
+        torch.cuda.synchronize()
+        reps = 100
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            kernels.hamming_knn2_ratio(q, t, 0.8, out=out)
+        torch.cuda.synchronize()
+        call_us = (time.perf_counter() - t0) / reps * 1e6
+        _lib.check(_lib.lib.slamhip_profile_begin(reps), "profile_begin")
+        for _ in range(reps):
+            kernels.hamming_knn2_ratio(q, t, 0.8, out=out)
+        torch.cuda.synchronize()
+        ms = C.c_double(0.0)
+        k = _lib.lib.slamhip_profile_end(C.byref(ms))
+        kern_us = ms.value / max(k, 1) * 1e3
+        res = tuple(o.clone() for o in out)
+        if ref is None:
+            ref = res
+        same = all(torch.equal(a, b) for a, b in zip(ref, res))
+        key = (v, s)
+        if key not in best or kern_us < best[key][1]:
+            best[key] = (call_us, kern_us, same)
+tune(0, -1); tune(1, 0)
+for (v, s), (call_us, kern_us, same) in best.items():
+    print(f"n={n} D={D} variant {v:2d} splits {s:2d}: call {call_us:7.1f} us  kernel {kern_us:7.1f} us  "
+          f"{n * n / (kern_us * 1e-6):.3e} compares/s  same_as_popcount={same}", flush=True)
