@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libslamhip.so")
+# SLAMHIP_LIB_PATH points at another build of the same library (kernel experiments).
+LIB_PATH = os.environ.get("SLAMHIP_LIB_PATH") or os.path.join(_HERE, "libslamhip.so")
 
 OK, EINVAL, EUNSUPPORTED, EWORKSPACE, ELAUNCH = 0, -1, -2, -3, -4
 

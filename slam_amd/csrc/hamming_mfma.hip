@@ -33,6 +33,10 @@
 // k-step), so whatever order the instruction gives the 64 k positions is the same for A and B.
 #include "common.h"
 
+#ifndef SLAMHIP_ABLATE
+#define SLAMHIP_ABLATE 0
+#endif
+
 namespace {
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -67,12 +71,19 @@ __device__ __forceinline__ float kmax(float a, float b) {
 }
 
 // one packed dword -> 32 FP4 values (16 bytes): nibble j of word p = bit 4 j + p
-__device__ __forceinline__ v4i expand_dword(uint32_t x) {
+// (v_and_or_b32 takes no literal operands on gfx9, and the compiler splits the expression into
+// an and and an or when the masks are literals: the masks are passed in registers instead.)
+__device__ __forceinline__ uint32_t and_or(uint32_t x, uint32_t m, uint32_t o) {
+  uint32_t r;
+  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(m), "v"(o));   // one scalar operand at most
+  return r;
+}
+__device__ __forceinline__ v4i expand_dword(uint32_t x, uint32_t m8, uint32_t m2) {
   v4i o;
-  o[0] = (int)(((x << 3) & 0x88888888u) | 0x22222222u);
-  o[1] = (int)(((x << 2) & 0x88888888u) | 0x22222222u);
-  o[2] = (int)(((x << 1) & 0x88888888u) | 0x22222222u);
-  o[3] = (int)((x & 0x88888888u) | 0x22222222u);
+  o[0] = (int)and_or(x << 3, m8, m2);
+  o[1] = (int)and_or(x << 2, m8, m2);
+  o[2] = (int)and_or(x << 1, m8, m2);
+  o[3] = (int)and_or(x, m8, m2);
   return o;
 }
 
@@ -92,8 +103,9 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
   constexpr int D = 32 * W;
   constexpr int kStageSlots = R * CPR;                 // 16-byte slots per stage buffer
-  // one LDS object: two stage buffers, then two C_in tables of R floats
-  __shared__ uint4 lds[2 * kStageSlots + 2 * R / 4];
+  // one LDS object: two stage buffers, then two C_in tables (one float per thread, the first
+  // R of which are the stage's rows: every thread writes, so the loop body has no branch)
+  __shared__ uint4 lds[2 * kStageSlots + 2 * kThreads / 4];
   float *ctab = reinterpret_cast<float *>(lds + 2 * kStageSlots);
 
   const int pair = blockIdx.z;
@@ -110,14 +122,25 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
 
   const int n_splits = gridDim.y;
   const int split = blockIdx.y;
-  // whole tiles per split, so that a split starts on a packed row boundary the stage
-  // loads can take 16 bytes at a time from; the host keeps a split within MASK + 1 rows
+  // whole tiles per split; the host keeps a split within MASK + 1 rows
   int rps = (nt + n_splits - 1) / n_splits;
   rps = (rps + 31) & ~31;
   const int r_begin = min(nt, split * rps);
   const int r_end = min(nt, r_begin + rps);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+#if (SLAMHIP_ABLATE & 8)   // timing experiment: shader-clock stamps of one wave per block, written over idx2
+  unsigned long long stamp[40];
+  int n_stamp = 0;
+#define SLAMHIP_STAMP() do { if (n_stamp < 40) stamp[n_stamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SLAMHIP_STAMP() do { } while (0)
+#endif
+  SLAMHIP_STAMP();
+#if (SLAMHIP_ABLATE & 8)
+  const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const uint32_t m8 = 0x88888888u, m2 = 0x22222222u;
 
   // ---- queries -> expanded B fragments in registers
   v8i bq[G][KS];
@@ -128,7 +151,7 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     const uint32_t *src = qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const v4i e = expand_dword(src[2 * s + h]);
+      const v4i e = expand_dword(src[2 * s + h], m8, m2);
       bq[g][s] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
     }
   }
@@ -138,87 +161,137 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
 #pragma unroll
   for (int g = 0; g < G; ++g) b1[g] = b2[g] = -1.0f;             // negative: no key yet
 
-  // ---- per-lane LDS read offsets (bytes) of the A fragment of k-step s inside a tile
-  const int fr = row_swizzle<W>(r);
-  int aoff[KS];
+  if (r_begin < r_end) {
+    // ---- per-lane LDS byte offsets: A fragment of k-step s inside a tile, C_in quads
+    const int fr = row_swizzle<W>(r);
+    int aoff[KS];
 #pragma unroll
-  for (int s = 0; s < KS; ++s) aoff[s] = (r * CPR + ((2 * s + h) ^ fr)) * 16;
+    for (int s = 0; s < KS; ++s) aoff[s] = (r * CPR + ((2 * s + h) ^ fr)) * 16;
+    const int coff = 2 * kStageSlots * 16 + 16 * h;
 
-  // ---- stage loader: thread handles UNITS packed 16-byte units (4 dwords of one row)
-  auto load_stage = [&](int stage_begin, uint4 (&u)[GEO::UNITS]) {
+    // ---- stage staging: a thread owns UNITS packed 16-byte units (4 dwords of one row) per stage
+    int u_row[GEO::UNITS], u_dst[GEO::UNITS][4];
 #pragma unroll
     for (int k = 0; k < GEO::UNITS; ++k) {
       const int unit = tid + k * kThreads;
       const int row = unit / (W / 4), c4 = unit % (W / 4);
-      const int grow = min(stage_begin + row, r_end - 1);       // rows past the end: re-read the last
-      u[k] = *reinterpret_cast<const uint4 *>(tp + (size_t)(t0 + grow) * W + 4 * c4);
-    }
-  };
-  auto store_stage = [&](int buf, int stage_begin, const uint4 (&u)[GEO::UNITS]) {
-    uint4 *dst = lds + buf * kStageSlots;
-#pragma unroll
-    for (int k = 0; k < GEO::UNITS; ++k) {
-      const int unit = tid + k * kThreads;
-      const int row = unit / (W / 4), c4 = unit % (W / 4);
+      u_row[k] = row;
       const int f = row_swizzle<W>(row);
-      const uint32_t x[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) u_dst[k][j] = (row * CPR + ((4 * c4 + j) ^ f)) * 16;
+    }
+    const uint32_t *tbase = tp + (size_t)t0 * W + 4 * ((tid % (W / 4)));
+    char *const lbase = reinterpret_cast<char *>(lds);
+    uint4 u[GEO::UNITS];
+    auto load_stage = [&](int stage_begin) {
+#pragma unroll
+      for (int k = 0; k < GEO::UNITS; ++k) {
+        const int grow = min(stage_begin + u_row[k], r_end - 1);   // rows past the end: the last row again
+        u[k] = *reinterpret_cast<const uint4 *>(tbase + (size_t)grow * W);
+      }
+    };
+    auto store_stage = [&](int buf, int stage_begin) {
+      char *dst = lbase + buf * (kStageSlots * 16);
+#pragma unroll
+      for (int k = 0; k < GEO::UNITS; ++k) {
+        const uint32_t x[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          *reinterpret_cast<v4i *>(dst + u_dst[k][j]) = expand_dword(x[j], m8, m2);
+      }
+      const int lrow = stage_begin - r_begin + tid;                 // row index inside the split
+      ctab[buf * kThreads + tid] = (stage_begin + tid < r_end)
+                                       ? (float)((D << (SH - 1)) + (MASK - lrow)) : -1.0e30f;
+    };
+    // One tile: KS matrix instructions per query group into `acc`, C_in from the stage's
+    // table, interleaved with the vector ALU's fold of the PREVIOUS tile's keys `old` into
+    // the running top-2 (the two overlap inside the wave, and the fold never starts by
+    // waiting for the matrix pipe to drain).  One basic block; the scheduling hints ask for
+    // matrix instruction / vector instructions in alternation.
+    auto tile_step = [&](const char *sbase, const char *cbase, int tile, v16f (&acc)[G], const v16f (&old)[G]) {
+      v16f cin;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const v4i e = expand_dword(x[j]);
-        dst[row * CPR + ((4 * c4 + j) ^ f)] = make_uint4((uint32_t)e[0], (uint32_t)e[1], (uint32_t)e[2], (uint32_t)e[3]);
+        const float4 c = *reinterpret_cast<const float4 *>(cbase + (tile * 32 + 8 * j) * 4);
+        cin[4 * j + 0] = c.x; cin[4 * j + 1] = c.y; cin[4 * j + 2] = c.z; cin[4 * j + 3] = c.w;
       }
-    }
-    if (tid < R) {
-      const int lrow = stage_begin - r_begin + tid;               // row index inside the split
-      ctab[buf * R + tid] = (stage_begin + tid < r_end)
-                                ? (float)((D << (SH - 1)) + (MASK - lrow)) : -1.0e30f;
-    }
-  };
-
-  if (r_begin < r_end) {
-    uint4 u[GEO::UNITS];
-    load_stage(r_begin, u);
-    store_stage(0, r_begin, u);
-    __syncthreads();
-    int buf = 0;
-    for (int sb = r_begin; sb < r_end; sb += R, buf ^= 1) {
-      const bool more = sb + R < r_end;                            // block-uniform
-      if (more) load_stage(sb + R, u);
-      const char *base = reinterpret_cast<const char *>(lds + buf * kStageSlots);
-      const float *ct = ctab + buf * R;
-      const int rows = min(R, r_end - sb);
+      v4i a4[KS];
 #pragma unroll
-      for (int tile = 0; tile < R / 32; ++tile) {
-        if (tile * 32 < rows) {                                    // wave-uniform
-          v16f cin;
+      for (int s = 0; s < KS; ++s) a4[s] = *reinterpret_cast<const v4i *>(sbase + tile * 32 * CPR * 16 + aoff[s]);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float4 c = *reinterpret_cast<const float4 *>(ct + tile * 32 + 8 * j + 4 * h);
-            cin[4 * j + 0] = c.x; cin[4 * j + 1] = c.y; cin[4 * j + 2] = c.z; cin[4 * j + 3] = c.w;
-          }
-          v16f acc[G];
+      for (int s = 0; s < KS; ++s) {
+        const v8i a = v8i{a4[s][0], a4[s][1], a4[s][2], a4[s][3], 0, 0, 0, 0};
 #pragma unroll
-          for (int s = 0; s < KS; ++s) {
-            const v4i a4 = *reinterpret_cast<const v4i *>(base + tile * 32 * CPR * 16 + aoff[s]);
-            const v8i a = v8i{a4[0], a4[1], a4[2], a4[3], 0, 0, 0, 0};
-#pragma unroll
-            for (int g = 0; g < G; ++g)
-              acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[g][s], s == 0 ? cin : acc[g], 4, 4, 0,
-                                                                      scale_t, 0, scale_q);
-          }
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const float key = acc[g][i];
-              if (!BEST) b2[g] = fmed3(b1[g], b2[g], key);
-              b1[g] = kmax(b1[g], key);
-            }
-          }
+        for (int g = 0; g < G; ++g) {
+#if (SLAMHIP_ABLATE & 2) && defined(__HIP_DEVICE_COMPILE__)   // timing experiment: no matrix instructions
+          if (s == 0) acc[g] = cin;
+          asm volatile("" ::"v"(a4[s]), "v"(bq[g][s]));
+#else
+          acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[g][s], s == 0 ? cin : acc[g], 4, 4, 0,
+                                                                  scale_t, 0, scale_q);
+#endif
         }
       }
-      if (more) store_stage(buf ^ 1, sb + R, u);
+#if (SLAMHIP_ABLATE & 1) && defined(__HIP_DEVICE_COMPILE__)   // timing experiment: no fold (results kept alive)
+#pragma unroll
+      for (int g = 0; g < G; ++g) asm volatile("" ::"v"(old[g]));
+#else
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const float key = old[g][i];
+          if (!BEST) b2[g] = fmed3(b1[g], b2[g], key);
+          b1[g] = kmax(b1[g], key);
+        }
+      }
+#endif
+      constexpr int kValuPerMfma = (BEST ? 16 : 32) / KS;          // fold instructions per matrix instruction
+      __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);      // LDS reads first
+#pragma unroll
+      for (int k = 0; k < KS * G; ++k) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one matrix instruction
+        __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+
+    v16f accA[G], accB[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accB[g][i] = -1.0f;             // nothing to fold before the first tile
+    SLAMHIP_STAMP();
+    load_stage(r_begin);
+    store_stage(0, r_begin);
+    __syncthreads();
+    SLAMHIP_STAMP();
+    int buf = 0;
+    // Every stage runs whole: rows past the end carry a C_in that can never win.
+    for (int sb = r_begin; sb < r_end; sb += R, buf ^= 1) {
+      load_stage(sb + R);                                          // next stage (clamped rows when there is none)
+      const char *sbase = lbase + buf * (kStageSlots * 16);
+      const char *cbase = lbase + coff + buf * (kThreads * 4);
+#pragma unroll
+      for (int tile = 0; tile < R / 32; tile += 2) {
+        tile_step(sbase, cbase, tile, accA, accB);
+        SLAMHIP_STAMP();
+        tile_step(sbase, cbase, tile + 1, accB, accA);
+        SLAMHIP_STAMP();
+      }
+      store_stage(buf ^ 1, sb + R);
+      SLAMHIP_STAMP();
       __syncthreads();
+      SLAMHIP_STAMP();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const float key = accB[g][i];
+        if (!BEST) b2[g] = fmed3(b1[g], b2[g], key);
+        b1[g] = kmax(b1[g], key);
+      }
     }
   }
 
@@ -252,6 +325,16 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
       partial[(size_t)split * nq_total + row] = make_uint2(k1, k2);
     }
   }
+#if (SLAMHIP_ABLATE & 8)
+  SLAMHIP_STAMP();
+  const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && wave == 1 && blockIdx.z == 0) {
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    if (blk < 64)
+      for (int k = 0; k < 40; ++k) dist2[blk * 40 + k] = k < n_stamp ? (int)(stamp[k] - stamp[0]) : -1;
+    if (blk == 0) { dist2[64 * 40] = (int)(real1 - real0); dist2[64 * 40 + 1] = (int)(__builtin_amdgcn_s_memtime() - stamp[0]); }
+  }
+#endif
 }
 
 template <int W, int G, bool BEST>
