@@ -36,6 +36,9 @@
 #ifndef SLAMHIP_ABLATE
 #define SLAMHIP_ABLATE 0
 #endif
+#ifndef SLAMHIP_MFMA_STAGE_ROWS
+#define SLAMHIP_MFMA_STAGE_ROWS 128   // train rows per stage for 16-word rows (8-word rows: twice, 32-word rows: half)
+#endif
 
 namespace {
 
@@ -50,7 +53,7 @@ constexpr int kThreads = 256;
 template <int W> struct Geo {
   static constexpr int KS = W / 2;                    // matrix instructions per 32 x 32 tile
   static constexpr int CPR = W;                       // 16-byte chunks per expanded row
-  static constexpr int R = (W == 8) ? 128 : 64;       // train rows per stage
+  static constexpr int R = SLAMHIP_MFMA_STAGE_ROWS * (W == 8 ? 2 : 1) / (W == 32 ? 2 : 1);   // train rows per stage
   static constexpr int SH = (W == 32) ? 12 : 13;      // key = (D - d) << SH | (MASK - row)
   static constexpr int MASK = (1 << SH) - 1;
   static constexpr int UNITS = R * W / 4 / kThreads;  // 16-byte packed units per thread and stage
@@ -68,6 +71,32 @@ __device__ __forceinline__ float fmed3(float a, float b, float c) { return __bui
 // canonicalising instruction in front.
 __device__ __forceinline__ float kmax(float a, float b) {
   return __int_as_float(max(__float_as_int(a), __float_as_int(b)));
+}
+__device__ __forceinline__ float kmax3(float a, float b, float c) {   // v_max3_i32
+  return __int_as_float(max(max(__float_as_int(a), __float_as_int(b)), __float_as_int(c)));
+}
+// Folds a tile's 16 keys of one query into the running (best, second best), two keys at a
+// time, in 20 instructions (8 for the best alone) instead of 32:
+//   t_j   = med3(b1, x, y)      the middle of the running best and the two new keys
+//   b1    = max3(b1, x, y)
+//   b2    = max(b2, t_0 .. t_7)
+// Every t_j is the median of three keys seen so far, so it never exceeds the second largest
+// key S; and S is caught by the pair it arrives in (if the largest key came earlier or sits in
+// the same pair) or by the pair the largest key arrives in (S is the running best by then).
+template <bool BEST>
+__device__ __forceinline__ void fold16(const v16f &k, float &b1, float &b2) {
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (!BEST) t[j] = fmed3(b1, k[2 * j], k[2 * j + 1]);
+    b1 = kmax3(b1, k[2 * j], k[2 * j + 1]);
+  }
+  if (!BEST) {
+    b2 = kmax3(b2, t[0], t[1]);
+    b2 = kmax3(b2, t[2], t[3]);
+    b2 = kmax3(b2, t[4], t[5]);
+    b2 = kmax3(b2, t[6], t[7]);
+  }
 }
 
 // one packed dword -> 32 FP4 values (16 bytes): nibble j of word p = bit 4 j + p
@@ -129,44 +158,57 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
   const int r_end = min(nt, r_begin + rps);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-#if (SLAMHIP_ABLATE & 8)   // timing experiment: shader-clock stamps of one wave per block, written over idx2
-  unsigned long long stamp[40];
-  int n_stamp = 0;
-#define SLAMHIP_STAMP() do { if (n_stamp < 40) stamp[n_stamp++] = __builtin_amdgcn_s_memtime(); } while (0)
+#if (SLAMHIP_ABLATE & 8)   // timing experiment: shader-clock stamps of one wave of the first 64 blocks,
+                           // stored behind the last row of dist2 as they are taken
+  int *const stamp_out = dist2 + 2 * (size_t)nq_total + (blockIdx.y * gridDim.x + blockIdx.x) * 40;
+  const bool stamp_on = lane == 0 && wave == 1 && blockIdx.z == 0 && (blockIdx.y * gridDim.x + blockIdx.x) < 64;
+  const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+  int stamp_k = 0;
+#define SLAMHIP_STAMP() do { if (stamp_on && stamp_k < 40) stamp_out[stamp_k] = (int)(__builtin_amdgcn_s_memtime() - stamp0); ++stamp_k; } while (0)
 #else
 #define SLAMHIP_STAMP() do { } while (0)
 #endif
   SLAMHIP_STAMP();
-#if (SLAMHIP_ABLATE & 8)
-  const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
-#endif
   const uint32_t m8 = 0x88888888u, m2 = 0x22222222u;
 
-  // ---- queries -> expanded B fragments in registers
+  // ---- queries -> expanded B fragments in registers.  Lane half h takes dwords
+  // h * KS .. h * KS + KS - 1 of its row (k-step s <-> dword h * KS + s, on both operands):
+  // contiguous, so 16-byte loads.
   v8i bq[G][KS];
   int qrow[G];
+  uint4 qraw[G][KS / 4];
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     qrow[g] = qblk + (wave * G + g) * 32 + r;
-    const uint32_t *src = qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W;
+    const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W + h * KS);
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const v4i e = expand_dword(src[2 * s + h], m8, m2);
-      bq[g][s] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
-    }
+    for (int k = 0; k < KS / 4; ++k) qraw[g][k] = src[k];
   }
   const int scale_t = 127 + SH - 1, scale_q = 127;   // E8M0: 2^(SH-1) and 1
 
   float b1[G], b2[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) b1[g] = b2[g] = -1.0f;             // negative: no key yet
+  auto expand_queries = [&]() {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int k = 0; k < KS / 4; ++k) {
+        const uint32_t x[4] = {qraw[g][k].x, qraw[g][k].y, qraw[g][k].z, qraw[g][k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const v4i e = expand_dword(x[j], m8, m2);
+          bq[g][4 * k + j] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+        }
+      }
+  };
 
   if (r_begin < r_end) {
     // ---- per-lane LDS byte offsets: A fragment of k-step s inside a tile, C_in quads
     const int fr = row_swizzle<W>(r);
     int aoff[KS];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) aoff[s] = (r * CPR + ((2 * s + h) ^ fr)) * 16;
+    for (int s = 0; s < KS; ++s) aoff[s] = (r * CPR + ((h * KS + s) ^ fr)) * 16;
     const int coff = 2 * kStageSlots * 16 + 16 * h;
 
     // ---- stage staging: a thread owns UNITS packed 16-byte units (4 dwords of one row) per stage
@@ -237,16 +279,9 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
       for (int g = 0; g < G; ++g) asm volatile("" ::"v"(old[g]));
 #else
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const float key = old[g][i];
-          if (!BEST) b2[g] = fmed3(b1[g], b2[g], key);
-          b1[g] = kmax(b1[g], key);
-        }
-      }
+      for (int g = 0; g < G; ++g) fold16<BEST>(old[g], b1[g], b2[g]);
 #endif
-      constexpr int kValuPerMfma = (BEST ? 16 : 32) / KS;          // fold instructions per matrix instruction
+      constexpr int kValuPerMfma = ((BEST ? 8 : 20) + KS - 1) / KS;   // fold instructions per matrix instruction
       __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);      // LDS reads first
 #pragma unroll
       for (int k = 0; k < KS * G; ++k) {
@@ -262,14 +297,20 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
 #pragma unroll
       for (int i = 0; i < 16; ++i) accB[g][i] = -1.0f;             // nothing to fold before the first tile
     SLAMHIP_STAMP();
-    load_stage(r_begin);
+    load_stage(r_begin);                       // in flight while the queries are expanded
+    expand_queries();
     store_stage(0, r_begin);
+    load_stage(r_begin + R);
     __syncthreads();
     SLAMHIP_STAMP();
     int buf = 0;
     // Every stage runs whole: rows past the end carry a C_in that can never win.
     for (int sb = r_begin; sb < r_end; sb += R, buf ^= 1) {
-      load_stage(sb + R);                                          // next stage (clamped rows when there is none)
+      // the next stage (already in registers) goes to the other buffer, which nobody reads
+      // before the barrier below; then the stage after it is requested (rows clamped when
+      // there is none), with a whole stage of matrix work to arrive in
+      store_stage(buf ^ 1, sb + R);
+      load_stage(sb + 2 * R);
       const char *sbase = lbase + buf * (kStageSlots * 16);
       const char *cbase = lbase + coff + buf * (kThreads * 4);
 #pragma unroll
@@ -279,20 +320,12 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
         tile_step(sbase, cbase, tile + 1, accB, accA);
         SLAMHIP_STAMP();
       }
-      store_stage(buf ^ 1, sb + R);
       SLAMHIP_STAMP();
       __syncthreads();
       SLAMHIP_STAMP();
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const float key = accB[g][i];
-        if (!BEST) b2[g] = fmed3(b1[g], b2[g], key);
-        b1[g] = kmax(b1[g], key);
-      }
-    }
+    for (int g = 0; g < G; ++g) fold16<BEST>(accB[g], b1[g], b2[g]);
   }
 
   // ---- the two half-waves of a query meet; lane h == 0 writes
@@ -325,16 +358,7 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
       partial[(size_t)split * nq_total + row] = make_uint2(k1, k2);
     }
   }
-#if (SLAMHIP_ABLATE & 8)
   SLAMHIP_STAMP();
-  const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
-  if (lane == 0 && wave == 1 && blockIdx.z == 0) {
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
-    if (blk < 64)
-      for (int k = 0; k < 40; ++k) dist2[blk * 40 + k] = k < n_stamp ? (int)(stamp[k] - stamp[0]) : -1;
-    if (blk == 0) { dist2[64 * 40] = (int)(real1 - real0); dist2[64 * 40 + 1] = (int)(__builtin_amdgcn_s_memtime() - stamp[0]); }
-  }
-#endif
 }
 
 template <int W, int G, bool BEST>

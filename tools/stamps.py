@@ -1,23 +1,30 @@
 #!/usr/bin/env python3
-"""Prints the shader-clock stamps a diagnostics build of the matrix-core matcher
-(SLAMHIP_ABLATE=8, library named by SLAMHIP_LIB_PATH) leaves in idx2."""
-import os, sys, torch, numpy as np
+"""Prints the shader-clock stamps that a diagnostics build of the matrix-core matcher
+(SLAMHIP_ABLATE=8, library named by SLAMHIP_LIB_PATH) leaves behind the last row of dist2:
+    python tools/stamps.py [splits] [variant]"""
+import ctypes as C, os, sys, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from slam_amd import _lib, kernels
 from slam_amd.utils.synth import matcher_workload
+splits = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 n = 8192
 qn, tn = matcher_workload(n, n, 61, seed=3)
 q = kernels.to_device(qn, torch.uint8); t = kernels.to_device(tn, torch.uint8)
-_lib.lib.slamhip_tune(0, 10); _lib.lib.slamhip_tune(1, 1)      # one split: idx2 is written by the kernel itself
+_lib.lib.slamhip_tune(0, variant); _lib.lib.slamhip_tune(1, splits)
+extra = 64 * 40 + 8
+i2 = torch.zeros(2 * n + extra, dtype=torch.int32, device="cuda")
+d2 = torch.zeros(2 * n + extra, dtype=torch.int32, device="cuda")
+need = _lib.lib.slamhip_hamming_knn2_workspace_bytes(n, n, 1, n, n, 61)
+ws = torch.empty(need, dtype=torch.uint8, device="cuda")
 for _ in range(5):
-    i2, d2 = kernels.hamming_knn2(q, t)
+    rc = _lib.lib.slamhip_hamming_knn2(q.data_ptr(), n, t.data_ptr(), n, 61, 61, i2.data_ptr(), d2.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
 torch.cuda.synchronize()
-st = d2.cpu().numpy().reshape(-1)[:64 * 40].reshape(64, 40)
+tail = d2.cpu().numpy()[2 * n:]
+st = tail[:64 * 40].reshape(64, 40)
 np.set_printoptions(linewidth=250)
-cal = d2.cpu().numpy().reshape(-1)[64 * 40:64 * 40 + 2]
-print("whole block 0: realtime ticks (100 MHz)", cal[0], "memtime ticks", cal[1], "-> memtime MHz", cal[1] / max(cal[0], 1) * 100)
-for b in (0, 1, 5, 17, 31):
-    v = st[b]; v = v[v >= 0]
-    print("block", b, "stamps:", v[:3], "stage deltas (tile0, tile1, store, barrier):")
-    d = np.diff(v)
-    print(d[2:2 + 4 * 6].reshape(-1, 4), " total", v[-1])
+for b in (0, 1, 5, 17, 31, 40, 63):
+    v = st[b]; v = v[v > 0]
+    print("block", b, "stamps:", v)
