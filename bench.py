@@ -11,12 +11,17 @@ and the max-over-ranks of the time) matches its own independent descriptor
 pair: pairs shard with no data-path collective, so scaling is weak.
 
 Prints ONE JSON line on rank 0.  `value` = Hamming compares per second over all
-ranks.  `roofline` prices the dominant kernel (hamming_top2_kernel) in int32
-VALU lane-operations: 2*ceil(D/4) = 32 per compare (16 v_xor_b32 + 16
-v_bcnt_u32_b32).  On gfx950 a SIMD issues v_xor_b32 at 32 lanes per clock and
-v_bcnt_u32_b32 at 16 (tools/issue_probe2.hip, profiles/r1/issue_probe2.log), so
-a wave needs 16 x 2 + 16 x 4 = 96 cycles per train row: peak = 1024 SIMDs x 64
-compares / 96 cycles x 2.4 GHz = 1.64e12 compares/s = 52.4 Tlane-op/s.
+ranks.  `roofline` prices the dominant kernel.  With the matrix-core matcher
+(hamming_mfma_kernel, the default) a compare is a dot product of two rows of
++-1 FP4 values, one multiply-add per descriptor bit: 2 x 8 x 61 = 976 flop per
+compare (1024 issued: rows are padded to 64 bytes), against the ~10 PFLOP/s
+dense FP4 rate of v_mfma_scale_f32_32x32x64_f8f6f4.  With the popcount matcher
+(SLAMHIP_MATCHER=popcount, hamming_top2_kernel) a compare is 2*ceil(D/4) = 32
+int32 VALU lane-operations (16 v_xor_b32 + 16 v_bcnt_u32_b32), against the
+78.6 Tlane-op/s of a SIMD that issues 32 lanes per clock; the measured issue
+ceiling of that instruction mix (tools/issue_probe2.hip,
+profiles/r1/issue_probe2.log: v_bcnt_u32_b32 issues at 16 lanes per clock) is
+52.4 T and reported beside it.
 `cpu_baseline` times the C/OpenMP restatement (oracle/hamming_oracle.c) of the
 same workload on the host cores of this machine.
 """
@@ -58,6 +63,58 @@ PEAK_LANE_OPS = peak_compares_per_sec(DESC_BYTES) * 2 * ((DESC_BYTES + 3) // 4) 
 # FETCH_SIZE 2327 KB x2 (gfx950 wide-read correction) + WRITE_SIZE 4096 KB.
 PMC_TRAFFIC_BYTES = (2327 * 2 + 4096) * 1024
 OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
+# Matrix-core matcher: one multiply-add per descriptor bit; the instruction stream pads rows to
+# 8 / 16 / 32 dwords.  Peak: MI355X block-scaled FP4 MFMA, dense (no sparsity).
+MFMA_PEAK_FLOPS = 10.0e15
+# HBM-side bytes per matrix-core top-2 launch, same recipe (profiles/r2/pmc_matcher8k_mfma.txt):
+# FETCH_SIZE 2363 KB x2 + WRITE_SIZE 1024 KB.
+PMC_TRAFFIC_BYTES_MFMA = (2363 * 2 + 1024) * 1024
+
+
+def flop_per_compare(desc_bytes, issued=False):
+    if issued:
+        words = 8 if desc_bytes <= 32 else (16 if desc_bytes <= 64 else 32)
+        return 2 * 32 * words
+    return 2 * 8 * desc_bytes
+
+
+def matcher_roofline(mfma, compares, kernel_s, n_launch, desc_bytes=DESC_BYTES):
+    """The `roofline` object of a stretch of top-2 kernel launches that did `compares`
+    Hamming compares per launch and took `kernel_s` seconds per launch (HIP events on the
+    launch stream)."""
+    hbm = {"hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9, "hbm_peak_GBps": 8000.0,
+           "hbm_frac": HBM_BYTES_PER_CALL / kernel_s / 8e12}
+    if mfma:
+        achieved = compares * flop_per_compare(desc_bytes) / kernel_s
+        issued = compares * flop_per_compare(desc_bytes, True) / kernel_s
+        return {"bound": "mfma", "kernel": "hamming_mfma_kernel",
+                "achieved": achieved / 1e12, "peak": MFMA_PEAK_FLOPS / 1e12, "unit": "TFLOP/s",
+                "frac": achieved / MFMA_PEAK_FLOPS,
+                "flop_per_compare": flop_per_compare(desc_bytes),
+                "peak_source": "MI355X_MICROARCH.md: FP4 block-scaled MFMA ~10 PF dense "
+                               "(v_mfma_scale_f32_32x32x64_f8f6f4, 32 cycles per SIMD at 2.4 GHz)",
+                "achieved_issued": issued / 1e12, "frac_issued": issued / MFMA_PEAK_FLOPS,
+                "issued_note": f"{flop_per_compare(desc_bytes, True)} flop per compare pass through "
+                               "the matrix cores: rows are zero padded to 64 bytes",
+                "kernel_us": kernel_s * 1e6, "launches_timed": n_launch, **hbm,
+                "traffic": PMC_TRAFFIC_BYTES_MFMA,
+                "traffic_source": "profiles/r2/pmc_matcher8k_mfma.txt (separate rocprofv3 --pmc passes of "
+                                  "the same call, not read in this run): FETCH_SIZE x2 + WRITE_SIZE; "
+                                  "includes the 1 MB of split results the kernel writes for the merge"}
+    achieved = compares * OPS_PER_COMPARE / kernel_s
+    return {"bound": "valu-int32", "kernel": "hamming_top2_kernel",
+            "achieved": achieved / 1e12, "peak": UNIFORM_PEAK_LANE_OPS / 1e12,
+            "unit": "Tlane-op/s", "frac": achieved / UNIFORM_PEAK_LANE_OPS,
+            "ops_per_compare": OPS_PER_COMPARE,
+            "peak_source": "MI355X_MICROARCH.md: 1024 SIMDs x 32 lanes per clock x 2.4 GHz",
+            "frac_of_measured_issue_ceiling": achieved / PEAK_LANE_OPS,
+            "measured_issue_ceiling": PEAK_LANE_OPS / 1e12,
+            "measured_issue_ceiling_source": "profiles/r1/issue_probe2.log: 16 v_xor_b32 at 2 cycles + 16 "
+                                             "v_bcnt_u32_b32 at 4 cycles per wave64 and train row",
+            "kernel_us": kernel_s * 1e6, "launches_timed": n_launch, **hbm,
+            "traffic": PMC_TRAFFIC_BYTES,
+            "traffic_source": "profiles/r1/pmc_matcher8k_v.txt (separate rocprofv3 --pmc passes, not read "
+                              "in this run); includes the 4 MB of split results the kernel writes"}
 HBM_BYTES_PER_CALL = (NQ + NT) * DESC_BYTES + NQ * 16 + NQ   # read descriptors, write idx2/dist2/keep
 
 
@@ -147,6 +204,26 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
         return None
     h = res.to_host()
     info = h["ransac_info"].reshape(-1, 8)
+    # dominant kernel of the pass: the matcher's top-2 kernel (stereo pairs, then temporal
+    # pairs); one more pass with its launches bracketed by HIP events on the launch stream
+    from slam_amd import _lib
+    _lib.check(_lib.lib.slamhip_profile_begin(64), "slamhip_profile_begin")
+    fe.run(inputs)
+    torch.cuda.synchronize()
+    tot_ms = C.c_double(0.0)
+    n_launch = _lib.lib.slamhip_profile_end(C.byref(tot_ms))
+    stc = h["st_count"][:F].astype(np.float64)
+    n_feat = np.array([[len(fr[0]), len(fr[1])] for fr in frames], dtype=np.float64)
+    compares_pass = float((n_feat[:, 0] * n_feat[:, 1]).sum() + (stc[1:] * stc[:-1]).sum())
+    mfma = _lib.lib.slamhip_matcher_kind() == 1
+    roof = matcher_roofline(mfma, compares_pass, max(tot_ms.value, 1e-9) * 1e-3, n_launch)
+    for k in ("hbm_algorithmic_GBps", "hbm_peak_GBps", "hbm_frac", "traffic", "traffic_source"):
+        roof.pop(k, None)
+    roof["kernel"] += "<best only> (k=1)"
+    roof["compares_per_pass"] = compares_pass
+    roof["kernel_us"] = tot_ms.value * 1e3
+    roof["kernel_us_note"] = f"sum over the {n_launch} top-2 launches of one pass (stereo batch, temporal batch)"
+    roof["share_of_pass"] = tot_ms.value * 1e-3 / (elapsed / args.frontend_steps)
     out = {
         "metric": "frontend_frames_per_sec",
         "value": F * args.frontend_steps * world / elapsed,
@@ -163,6 +240,7 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
         "ransac_iterations_mean": float(info[:, 2].mean()),
         "pose_error_vs_truth_max_m": float(max(
             np.abs(res.pair(p)["Rt"][:, 3] - seq.relative_pose(p + 1)[:, 3]).max() for p in range(0, F - 1, 25))),
+        "roofline": roof,
     }
     # The same pass with the host on both sides: features start in host memory
     # (concatenate + H2D) and every result array is copied back (D2H).
@@ -205,7 +283,7 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
     return out
 
 
-def bench_sweep(kernels):
+def bench_sweep(kernels, mfma=False):
     """Matcher alone at the other sizes the workload family covers (one pair,
     inputs resident): N in {2048, 4096, 8192} x D in {61 (AKAZE), 32 (ORB)}."""
     from slam_amd.utils.synth import matcher_workload
@@ -227,10 +305,12 @@ def bench_sweep(kernels):
                 kernels.hamming_knn2_ratio(q, t, RATIO, out=out)
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
-            ops = 2 * ((nbytes + 3) // 4)
+            if mfma:    # whole call (pack + top-2 + merge) against the FP4 matrix-core peak
+                frac = n * n * flop_per_compare(nbytes) / dt / MFMA_PEAK_FLOPS
+            else:       # ... against the 2-cycle VALU rate
+                frac = n * n * 2 * ((nbytes + 3) // 4) / dt / UNIFORM_PEAK_LANE_OPS
             rows.append({"n": n, "desc_bytes": nbytes, "us_per_call": dt * 1e6,
-                         "compares_per_sec": n * n / dt,
-                         "frac_of_peak": n * n / dt / peak_compares_per_sec(nbytes)})
+                         "compares_per_sec": n * n / dt, "frac_of_peak": frac})
     return rows
 
 
@@ -389,6 +469,7 @@ def main():
 
     from slam_amd import _lib, kernels
     from slam_amd.utils.synth import matcher_workload
+    mfma = _lib.lib.slamhip_matcher_kind() == 1
 
     q_np, t_np = matcher_workload(NQ, NT, DESC_BYTES, seed=rank)
     q = kernels.to_device(q_np, torch.uint8)
@@ -444,7 +525,6 @@ def main():
     line = None
     if rank == 0:
         compares = float(NQ) * NT
-        achieved = compares * OPS_PER_COMPARE / kernel_s
         line = {
             "metric": "hamming_compares_per_sec",
             "value": compares * args.steps * world / elapsed,
@@ -458,28 +538,15 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32 (xor+popcount)",
+            "dtype": ("fp4 e2m1 (+-1 per descriptor bit) products, f32 accumulation of exact integers"
+                      if mfma else "u32 (xor+popcount)"),
+            "matcher": "mfma" if mfma else "popcount",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 8192x8192 AKAZE 61-byte descriptors, "
                                    "brute-force Hamming kNN(k=2) + ratio test, one pair per GPU",
                        "nq": NQ, "nt": NT, "desc_bytes": DESC_BYTES, "ratio": RATIO,
                        "parallelism": f"independent pairs x{world}"},
-            "roofline": {"bound": "valu-int32", "kernel": "hamming_top2_kernel",
-                         "achieved": achieved / 1e12, "peak": PEAK_LANE_OPS / 1e12,
-                         "unit": "Tlane-op/s", "frac": achieved / PEAK_LANE_OPS,
-                         "ops_per_compare": OPS_PER_COMPARE,
-                         "peak_model": "16 v_xor_b32 at 2 cycles + 16 v_bcnt_u32_b32 at 4 cycles per wave64 "
-                                       "and train row (issue rates measured with tools/issue_probe2.hip) "
-                                       "on 1024 SIMDs at 2.4 GHz = 1.64e12 compares/s",
-                         "kernel_us": kernel_s * 1e6, "launches_timed": n_launch,
-                         "frac_if_every_op_issued_in_2_cycles": achieved / UNIFORM_PEAK_LANE_OPS,
-                         "hbm_algorithmic_GBps": HBM_BYTES_PER_CALL / kernel_s / 1e9,
-                         "hbm_peak_GBps": 8000.0,
-                         "hbm_frac": HBM_BYTES_PER_CALL / kernel_s / 8e12,
-                         "traffic": PMC_TRAFFIC_BYTES,
-                         "traffic_note": "bytes per launch from separate rocprofv3 --pmc passes "
-                                         "(profiles/r1/pmc_matcher8k_v.txt); includes the 4 MB of "
-                                         "split results the kernel writes for the merge"},
+            "roofline": matcher_roofline(mfma, compares, kernel_s, n_launch),
         }
     # The secondary sections exchange records between ranks.  The primary measurement is
     # complete at this point: if a section fails on one rank (the others would then wait in
@@ -516,7 +583,7 @@ def main():
 
     if rank == 0:
         if world == 1 and not args.no_sweep:
-            line["sweep"] = bench_sweep(kernels)
+            line["sweep"] = bench_sweep(kernels, mfma)
             line["l2_matcher"] = bench_l2(kernels)
         if frontend is not None:
             line["frontend"] = frontend

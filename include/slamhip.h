@@ -53,16 +53,24 @@ int slamhip_version(void);
 const char *slamhip_strerror(int code);
 
 /* Diagnostics only (kernel-variant benchmarks): knob 0 = matcher kernel variant
- * (-1 auto), knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
+ * (-1 auto; 0..5 popcount kernels; 8 matrix-core kernel, 9 / 10 / 12 the same with
+ * 1 / 2 / 4 groups of 32 queries per wave), knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
  * screening in the consensus counting kernels (1 = on, the default; 0 = fp64 only;
  * the counts are identical either way), knob 3 = matcher block size (0 auto, 256 or
  * 128 queries per block), knob 4 = pair RANSAC launch scheme (0 auto: calls with at
  * most 64 pairs solve and count every hypothesis in one pass; 1 always rounds of 256
  * hypotheses; identical results; set it before sizing a workspace), knob 5 = sort
  * algorithm (0 auto, 1 rank counting, 2 bitonic network where the segments fit it;
- * same order).  Process-global; not for use while other threads are inside the
- * library. */
+ * same order), knob 6 / 7 = matrix-core matcher: blocks a launch aims at / train rows
+ * per block it does not exceed when blocks abound (0 = default).  Process-global; not
+ * for use while other threads are inside the library. */
 int slamhip_tune(int knob, int value);
+
+/* Which kernel family the Hamming matcher uses when knob 0 forces nothing:
+ * 1 = matrix cores (FP4 block-scaled MFMA emits the sort key), 0 = xor + popcount on
+ * the vector ALU.  Both give the same results bit for bit.  The environment variable
+ * SLAMHIP_MATCHER ("mfma" / "popcount"), read once, overrides the built-in default. */
+int slamhip_matcher_kind(void);
 
 /* Diagnostics only: kernel-duration probe.  After begin(max_launches) the
  * matcher brackets its top-2 kernel with HIP events recorded on the launch

@@ -46,6 +46,7 @@ SIGNATURES = {
     "slamhip_version": (_i, []),
     "slamhip_strerror": (C.c_char_p, [_i]),
     "slamhip_tune": (_i, [_i, _i]),
+    "slamhip_matcher_kind": (_i, []),
     "slamhip_profile_begin": (_i, [_i]),
     "slamhip_profile_end": (_i, [_dp]),
     "slamhip_hamming_knn2_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i]),

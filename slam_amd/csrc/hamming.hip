@@ -889,6 +889,8 @@ int slamhip_tune(int knob, int value) {
   return SLAMHIP_OK;
 }
 
+int slamhip_matcher_kind(void) { return default_mfma() ? 1 : 0; }
+
 // Kernel-duration probe for benchmarks.  begin(max_launches): from now on the
 // matcher brackets its top-2 kernel with HIP events on the launch stream (at
 // most max_launches of them).  end(): synchronises those events, returns the

@@ -252,11 +252,16 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     // matrix instruction / vector instructions in alternation.
     auto tile_step = [&](const char *sbase, const char *cbase, int tile, v16f (&acc)[G], const v16f (&old)[G]) {
       v16f cin;
+#if (SLAMHIP_ABLATE & 16)   // timing experiment: no C_in reads
+#pragma unroll
+      for (int j = 0; j < 16; ++j) cin[j] = 1.0f;
+#else
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 c = *reinterpret_cast<const float4 *>(cbase + (tile * 32 + 8 * j) * 4);
         cin[4 * j + 0] = c.x; cin[4 * j + 1] = c.y; cin[4 * j + 2] = c.z; cin[4 * j + 3] = c.w;
       }
+#endif
       v4i a4[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) a4[s] = *reinterpret_cast<const v4i *>(sbase + tile * 32 * CPR * 16 + aoff[s]);
@@ -309,8 +314,10 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
       // the next stage (already in registers) goes to the other buffer, which nobody reads
       // before the barrier below; then the stage after it is requested (rows clamped when
       // there is none), with a whole stage of matrix work to arrive in
+#if !(SLAMHIP_ABLATE & 4)   // timing experiment: the first stage is scanned again and again
       store_stage(buf ^ 1, sb + R);
       load_stage(sb + 2 * R);
+#endif
       const char *sbase = lbase + buf * (kStageSlots * 16);
       const char *cbase = lbase + coff + buf * (kThreads * 4);
 #pragma unroll

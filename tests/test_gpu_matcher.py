@@ -9,9 +9,12 @@ from oracle import slam_oracle as so
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True)
-def _reset_tuning():
+@pytest.fixture(autouse=True, params=["mfma", "popcount"])
+def _reset_tuning(request):
+    """Every test runs once per kernel family (tune knob 0: 8 = matrix-core kernel, 1 =
+    popcount kernel); tests that pick a variant themselves override it."""
     from slam_amd import _lib
+    _lib.lib.slamhip_tune(0, 8 if request.param == "mfma" else 1)
     yield
     _lib.lib.slamhip_tune(0, -1)
     _lib.lib.slamhip_tune(1, 0)
