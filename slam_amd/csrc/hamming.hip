@@ -619,7 +619,7 @@ struct ProfEvents {
 ProfEvents g_prof;
 
 // diagnostics: -1 auto; 0..7 popcount kernel variants (bit0 = LDS, bits 1.. = Q);
-// 8 = matrix-core kernel, 9 / 10 / 12 = the same with 1 / 2 / 4 query groups per wave
+// 8 = matrix-core kernel, 9 / 10 = the same with 1 / 2 query groups per wave
 int g_force_variant = -1;
 
 // Kernel family when nothing is forced: the environment variable SLAMHIP_MATCHER
@@ -667,13 +667,13 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
     // 4 waves x G groups of 32 queries per block; two groups unless one fills the last
     // block of a pair much better, or the registers do not allow more (32-word rows)
     int G = p.G;
-    if (G != 1 && G != 2 && G != 4) {
+    if (G != 1 && G != 2) {
       G = 2;
       const int idle2 = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 256) * 256 - max_nq;
       const int idle1 = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128) * 128 - max_nq;
       if (idle2 - idle1 >= 128 && idle2 * 8 > max_nq) G = 1;
     }
-    if (p.W == 32 && G > 2) G = 2;
+    if (p.W == 32) G = 1;   // the query fragments of two groups of 32-word rows do not fit the registers
     p.G = G;
     p.threads = kThreads;
     p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128 * G);

@@ -158,17 +158,16 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
   const int r_end = min(nt, r_begin + rps);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-#if (SLAMHIP_ABLATE & 8)   // timing experiment: shader-clock stamps of one wave of the first 64 blocks,
-                           // stored behind the last row of dist2 as they are taken
+#if (SLAMHIP_ABLATE & 32)  // timing experiment: lifetime of one wave of the first 64 blocks in shader
+                           // cycles and in 100 MHz ticks, stored behind the last row of dist2
   int *const stamp_out = dist2 + 2 * (size_t)nq_total + (blockIdx.y * gridDim.x + blockIdx.x) * 40;
   const bool stamp_on = lane == 0 && wave == 1 && blockIdx.z == 0 && (blockIdx.y * gridDim.x + blockIdx.x) < 64;
   const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
-  int stamp_k = 0;
-#define SLAMHIP_STAMP() do { if (stamp_on && stamp_k < 40) stamp_out[stamp_k] = (int)(__builtin_amdgcn_s_memtime() - stamp0); ++stamp_k; } while (0)
-#else
-#define SLAMHIP_STAMP() do { } while (0)
+  const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  SLAMHIP_STAMP();
+#if (SLAMHIP_ABLATE & 64)  // timing experiment: start and end of every block in 100 MHz ticks, behind dist2
+  const unsigned span0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
   const uint32_t m8 = 0x88888888u, m2 = 0x22222222u;
 
   // ---- queries -> expanded B fragments in registers.  Lane half h takes dwords
@@ -212,9 +211,10 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     const int coff = 2 * kStageSlots * 16 + 16 * h;
 
     // ---- stage staging: a thread owns UNITS packed 16-byte units (4 dwords of one row) per stage
-    int u_row[GEO::UNITS], u_dst[GEO::UNITS][4];
+    constexpr int UNITS = GEO::UNITS, PIECES = 4 * UNITS;   // a piece = one dword -> one 16-byte LDS slot
+    int u_row[UNITS], u_dst[UNITS][4];
 #pragma unroll
-    for (int k = 0; k < GEO::UNITS; ++k) {
+    for (int k = 0; k < UNITS; ++k) {
       const int unit = tid + k * kThreads;
       const int row = unit / (W / 4), c4 = unit % (W / 4);
       u_row[k] = row;
@@ -224,76 +224,101 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     }
     const uint32_t *tbase = tp + (size_t)t0 * W + 4 * ((tid % (W / 4)));
     char *const lbase = reinterpret_cast<char *>(lds);
-    uint4 u[GEO::UNITS];
+    uint32_t ux[PIECES];
     auto load_stage = [&](int stage_begin) {
 #pragma unroll
-      for (int k = 0; k < GEO::UNITS; ++k) {
+      for (int k = 0; k < UNITS; ++k) {
         const int grow = min(stage_begin + u_row[k], r_end - 1);   // rows past the end: the last row again
-        u[k] = *reinterpret_cast<const uint4 *>(tbase + (size_t)grow * W);
+        const uint4 v = *reinterpret_cast<const uint4 *>(tbase + (size_t)grow * W);
+        ux[4 * k + 0] = v.x; ux[4 * k + 1] = v.y; ux[4 * k + 2] = v.z; ux[4 * k + 3] = v.w;
       }
     };
-    auto store_stage = [&](int buf, int stage_begin) {
-      char *dst = lbase + buf * (kStageSlots * 16);
-#pragma unroll
-      for (int k = 0; k < GEO::UNITS; ++k) {
-        const uint32_t x[4] = {u[k].x, u[k].y, u[k].z, u[k].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          *reinterpret_cast<v4i *>(dst + u_dst[k][j]) = expand_dword(x[j], m8, m2);
-      }
+    auto store_piece = [&](char *dst, int p) {
+      *reinterpret_cast<v4i *>(dst + u_dst[p / 4][p % 4]) = expand_dword(ux[p], m8, m2);
+    };
+    // C_in of the stage's rows (one float per thread, the first R of them are rows: every thread
+    // writes, so there is no branch); rows past the end get a value that can never win
+    auto store_ctab = [&](int buf, int stage_begin) {
       const int lrow = stage_begin - r_begin + tid;                 // row index inside the split
       ctab[buf * kThreads + tid] = (stage_begin + tid < r_end)
                                        ? (float)((D << (SH - 1)) + (MASK - lrow)) : -1.0e30f;
     };
-    // One tile: KS matrix instructions per query group into `acc`, C_in from the stage's
-    // table, interleaved with the vector ALU's fold of the PREVIOUS tile's keys `old` into
-    // the running top-2 (the two overlap inside the wave, and the fold never starts by
-    // waiting for the matrix pipe to drain).  One basic block; the scheduling hints ask for
-    // matrix instruction / vector instructions in alternation.
-    auto tile_step = [&](const char *sbase, const char *cbase, int tile, v16f (&acc)[G], const v16f (&old)[G]) {
-      v16f cin;
-#if (SLAMHIP_ABLATE & 16)   // timing experiment: no C_in reads
-#pragma unroll
-      for (int j = 0; j < 16; ++j) cin[j] = 1.0f;
-#else
+    auto read_cin = [&](const char *cbase, int tile) {
+      v16f c;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float4 c = *reinterpret_cast<const float4 *>(cbase + (tile * 32 + 8 * j) * 4);
-        cin[4 * j + 0] = c.x; cin[4 * j + 1] = c.y; cin[4 * j + 2] = c.z; cin[4 * j + 3] = c.w;
+        const float4 q4 = *reinterpret_cast<const float4 *>(cbase + (tile * 32 + 8 * j) * 4);
+        c[4 * j + 0] = q4.x; c[4 * j + 1] = q4.y; c[4 * j + 2] = q4.z; c[4 * j + 3] = q4.w;
       }
-#endif
-      v4i a4[KS];
+      return c;
+    };
+
+    // ---- software pipeline.  The wave always holds the A fragments `a` and the C_in `cin` of
+    // the tile it is about to multiply; each k-step issues its G matrix instructions, then
+    // re-fills the fragment register it has just used with the same k-step of the NEXT tile,
+    // then does a slice of the vector work: the top-2 fold of the PREVIOUS tile's keys `old`,
+    // and one piece of the next stage's expansion.  Nothing in the loop waits for LDS or
+    // memory it has only just asked for.
+    constexpr int T = R / 32;                      // tiles per stage
+    constexpr int SLOTS = (T - 1) * KS;            // k-steps before the stage's barrier
+    static_assert(T >= 2 && SLOTS >= PIECES, "a stage has room for its staging pieces");
+    v4i a[KS];
+    v16f cin;
+    float tprev[G];
+    constexpr bool PIPE = W < 32;   // 32-word rows: the fragments alone are 64 registers, no room to run ahead
+    auto tile_step = [&](int tile, const char *cur_a, const char *cur_c, const char *pf_a, const char *pf_c,
+                         int pf_tile, char *st_dst, v16f (&acc)[G], const v16f (&old)[G]) {
+      if (!PIPE) {
 #pragma unroll
-      for (int s = 0; s < KS; ++s) a4[s] = *reinterpret_cast<const v4i *>(sbase + tile * 32 * CPR * 16 + aoff[s]);
+        for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const v4i *>(cur_a + tile * 32 * CPR * 16 + aoff[s]);
+        cin = read_cin(cur_c, tile);
+      }
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        const v8i a = v8i{a4[s][0], a4[s][1], a4[s][2], a4[s][3], 0, 0, 0, 0};
+        const v8i a8 = v8i{a[s][0], a[s][1], a[s][2], a[s][3], 0, 0, 0, 0};
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #if (SLAMHIP_ABLATE & 2) && defined(__HIP_DEVICE_COMPILE__)   // timing experiment: no matrix instructions
           if (s == 0) acc[g] = cin;
-          asm volatile("" ::"v"(a4[s]), "v"(bq[g][s]));
+          asm volatile("" ::"v"(a[s]), "v"(bq[g][s]));
 #else
-          acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, bq[g][s], s == 0 ? cin : acc[g], 4, 4, 0,
+          acc[g] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, bq[g][s], s == 0 ? cin : acc[g], 4, 4, 0,
                                                                   scale_t, 0, scale_q);
 #endif
         }
-      }
-#if (SLAMHIP_ABLATE & 1) && defined(__HIP_DEVICE_COMPILE__)   // timing experiment: no fold (results kept alive)
+        if (PIPE) {
+          a[s] = *reinterpret_cast<const v4i *>(pf_a + pf_tile * 32 * CPR * 16 + aoff[s]);
+          if (s == 0) cin = read_cin(pf_c, pf_tile);
+        }
+        // fold: the 8 key pairs of `old` spread over the KS steps
+#if !(SLAMHIP_ABLATE & 1)
 #pragma unroll
-      for (int g = 0; g < G; ++g) asm volatile("" ::"v"(old[g]));
+        for (int j = s * 8 / KS; j < (s + 1) * 8 / KS; ++j) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const float x = old[g][2 * j], y = old[g][2 * j + 1];
+            if (!BEST) {
+              const float t = fmed3(b1[g], x, y);
+              if (j & 1) b2[g] = kmax3(b2[g], tprev[g], t);
+              else tprev[g] = t;
+            }
+            b1[g] = kmax3(b1[g], x, y);
+          }
+        }
 #else
+        if (s == 0)
 #pragma unroll
-      for (int g = 0; g < G; ++g) fold16<BEST>(old[g], b1[g], b2[g]);
+          for (int g = 0; g < G; ++g) asm volatile("" ::"v"(old[g]));
 #endif
-      constexpr int kValuPerMfma = ((BEST ? 8 : 20) + KS - 1) / KS;   // fold instructions per matrix instruction
-      __builtin_amdgcn_sched_group_barrier(0x100, KS + 4, 0);      // LDS reads first
+        // staging: piece p of the next stage in k-step p * SLOTS / PIECES of this stage
+        const int slot = tile * KS + s;
+        if (tile < T - 1) {
 #pragma unroll
-      for (int k = 0; k < KS * G; ++k) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);         // one matrix instruction
-        __builtin_amdgcn_sched_group_barrier(0x002, kValuPerMfma, 0);
+          for (int p = 0; p < PIECES; ++p)
+            if (p * SLOTS / PIECES == slot) store_piece(st_dst, p);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     };
 
     v16f accA[G], accB[G];
@@ -301,35 +326,42 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     for (int g = 0; g < G; ++g)
 #pragma unroll
       for (int i = 0; i < 16; ++i) accB[g][i] = -1.0f;             // nothing to fold before the first tile
-    SLAMHIP_STAMP();
     load_stage(r_begin);                       // in flight while the queries are expanded
     expand_queries();
-    store_stage(0, r_begin);
+#pragma unroll
+    for (int p = 0; p < PIECES; ++p) store_piece(lbase, p);
+    store_ctab(0, r_begin);
     load_stage(r_begin + R);
     __syncthreads();
-    SLAMHIP_STAMP();
+    if (PIPE) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const v4i *>(lbase + aoff[s]);
+      cin = read_cin(lbase + coff, 0);
+    }
     int buf = 0;
     // Every stage runs whole: rows past the end carry a C_in that can never win.
     for (int sb = r_begin; sb < r_end; sb += R, buf ^= 1) {
-      // the next stage (already in registers) goes to the other buffer, which nobody reads
-      // before the barrier below; then the stage after it is requested (rows clamped when
-      // there is none), with a whole stage of matrix work to arrive in
-#if !(SLAMHIP_ABLATE & 4)   // timing experiment: the first stage is scanned again and again
-      store_stage(buf ^ 1, sb + R);
-      load_stage(sb + 2 * R);
-#endif
       const char *sbase = lbase + buf * (kStageSlots * 16);
       const char *cbase = lbase + coff + buf * (kThreads * 4);
+      char *nbase = lbase + (buf ^ 1) * (kStageSlots * 16);
+      const char *ncbase = lbase + coff + (buf ^ 1) * (kThreads * 4);
+      // the next stage (in registers since the stage before) goes to the other buffer piece by
+      // piece during tiles 0 .. T-2; nobody reads that buffer before the barrier
+      store_ctab(buf ^ 1, sb + R);
 #pragma unroll
-      for (int tile = 0; tile < R / 32; tile += 2) {
-        tile_step(sbase, cbase, tile, accA, accB);
-        SLAMHIP_STAMP();
-        tile_step(sbase, cbase, tile + 1, accB, accA);
-        SLAMHIP_STAMP();
+      for (int tile = 0; tile < T; tile += 2) {
+        tile_step(tile, sbase, cbase, sbase, cbase, tile + 1, nbase, accA, accB);
+        if (tile + 2 == T) {
+          // every piece of the next stage is on its way to LDS: meet the other waves (after
+          // the barrier the next stage may be read and this one is no longer needed), and
+          // ask for the stage after it (rows clamped when there is none)
+          __syncthreads();
+          load_stage(sb + 2 * R);
+          tile_step(tile + 1, sbase, cbase, nbase, ncbase, 0, nbase, accB, accA);
+        } else {
+          tile_step(tile + 1, sbase, cbase, sbase, cbase, tile + 2, nbase, accB, accA);
+        }
       }
-      SLAMHIP_STAMP();
-      __syncthreads();
-      SLAMHIP_STAMP();
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) fold16<BEST>(accB[g], b1[g], b2[g]);
@@ -365,7 +397,24 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
       partial[(size_t)split * nq_total + row] = make_uint2(k1, k2);
     }
   }
-  SLAMHIP_STAMP();
+#if (SLAMHIP_ABLATE & 64)
+  if (tid == 0 && blockIdx.z == 0) {
+    int *o = dist2 + 2 * (size_t)nq_total + 4 * (blockIdx.y * gridDim.x + blockIdx.x);
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    o[0] = (int)span0;
+    o[1] = (int)(unsigned)__builtin_amdgcn_s_memrealtime();
+    o[2] = (int)xcc;
+    o[3] = (int)hw;
+  }
+#endif
+#if (SLAMHIP_ABLATE & 32)  // slots 38 / 39: the wave's lifetime in shader cycles and in 100 MHz ticks
+  if (stamp_on) {
+    stamp_out[38] = (int)(__builtin_amdgcn_s_memtime() - stamp0);
+    stamp_out[39] = (int)(__builtin_amdgcn_s_memrealtime() - real0);
+  }
+#endif
 }
 
 template <int W, int G, bool BEST>
@@ -394,9 +443,9 @@ void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, con
                                nq_total, (uint2 *)part, idx2, dist2);                                \
     return;                                                                                          \
   }
-  SLAMHIP_MFMA_CASE(8, 1) SLAMHIP_MFMA_CASE(8, 2) SLAMHIP_MFMA_CASE(8, 4)
-  SLAMHIP_MFMA_CASE(16, 1) SLAMHIP_MFMA_CASE(16, 2) SLAMHIP_MFMA_CASE(16, 4)
-  SLAMHIP_MFMA_CASE(32, 1) SLAMHIP_MFMA_CASE(32, 2)
+  SLAMHIP_MFMA_CASE(8, 1) SLAMHIP_MFMA_CASE(8, 2)
+  SLAMHIP_MFMA_CASE(16, 1) SLAMHIP_MFMA_CASE(16, 2)
+  SLAMHIP_MFMA_CASE(32, 1)
 #undef SLAMHIP_MFMA_CASE
 }
 

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Block start/end spread of the matrix-core matcher from a SLAMHIP_ABLATE=64 build (library named
+by SLAMHIP_LIB_PATH): first block start to last block end, against the kernel's event-timed duration.
+    python tools/span.py [splits] [variant] [n]"""
+import ctypes as C, os, sys, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from slam_amd import _lib, kernels
+from slam_amd.utils.synth import matcher_workload
+splits = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
+qn, tn = matcher_workload(n, n, 61, seed=3)
+q = kernels.to_device(qn, torch.uint8); t = kernels.to_device(tn, torch.uint8)
+_lib.lib.slamhip_tune(0, variant); _lib.lib.slamhip_tune(1, splits)
+extra = 4096
+i2 = torch.zeros(2 * n + extra, dtype=torch.int32, device="cuda")
+d2 = torch.zeros(2 * n + extra, dtype=torch.int32, device="cuda")
+need = _lib.lib.slamhip_hamming_knn2_workspace_bytes(n, n, 1, n, n, 61)
+ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+def call():
+    rc = _lib.lib.slamhip_hamming_knn2(q.data_ptr(), n, t.data_ptr(), n, 61, 61, i2.data_ptr(), d2.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+for _ in range(300):
+    call()
+torch.cuda.synchronize()
+_lib.check(_lib.lib.slamhip_profile_begin(100), "b")
+for _ in range(100):
+    call()
+torch.cuda.synchronize()
+ms = C.c_double(0.0)
+k = _lib.lib.slamhip_profile_end(C.byref(ms))
+tail = d2.cpu().numpy()[2 * n:].astype(np.int64) & 0xFFFFFFFF
+nb = (n // 256) * splits if variant == 10 else (n // 128) * splits
+rec = tail[:4 * nb].reshape(nb, 4)
+se = rec[:, :2]
+st, en = se[:, 0] - se[:, 0].min(), se[:, 1] - se[:, 0].min()
+print(f"event-timed kernel {ms.value / k * 1e3:.2f} us; blocks {nb}: start spread {st.max() / 100:.2f} us, "
+      f"first start -> last end {en.max() / 100:.2f} us, block lifetime median {np.median(en - st) / 100:.2f} "
+      f"min {(en - st).min() / 100:.2f} max {(en - st).max() / 100:.2f} us, first end {en.min() / 100:.2f} us")
+life = (en - st) / 100
+xcc = rec[:, 2] & 0xF
+hw = rec[:, 3]
+cu_key = xcc * 4096 + ((hw >> 13) & 7) * 256 + ((hw >> 12) & 1) * 16 + ((hw >> 8) & 0xF)
+keys, counts = np.unique(cu_key, return_counts=True)
+print("blocks per CU histogram:", dict(zip(*np.unique(counts, return_counts=True))), " distinct CUs:", len(keys))
+per_cu = dict(zip(keys, counts))
+nb_on_cu = np.array([per_cu[k] for k in cu_key])
+for c in np.unique(nb_on_cu):
+    m = nb_on_cu == c
+    print(f"  blocks on CUs holding {c}: n={m.sum()} lifetime median {np.median(life[m]):.2f} max {life[m].max():.2f} us")
+for x in range(8):
+    m = xcc == x
+    print(f"  xcc {x}: n={m.sum()} lifetime median {np.median(life[m]):.2f} max {life[m].max():.2f}, end max {en[m].max() / 100:.2f} us")
+qb = n // (256 if variant == 10 else 128)
+bid = np.arange(nb)
+print("  by split (median lifetime):", np.round([np.median(life[bid // qb == sp]) for sp in range(splits)], 2))

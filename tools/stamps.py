@@ -26,5 +26,8 @@ tail = d2.cpu().numpy()[2 * n:]
 st = tail[:64 * 40].reshape(64, 40)
 np.set_printoptions(linewidth=250)
 for b in (0, 1, 5, 17, 31, 40, 63):
-    v = st[b]; v = v[v > 0]
-    print("block", b, "stamps:", v)
+    v = st[b][:38]; v = v[v > 0]
+    print("block", b, "stamps:", v, " deltas:", np.diff(v))
+life = st[:, 38].astype(np.float64); real = st[:, 39].astype(np.float64)
+print("wave lifetime: shader cycles median", np.median(life), " 100 MHz ticks median", np.median(real),
+      " -> in-kernel clock %.0f MHz" % (np.median(life / np.maximum(real, 1)) * 100))

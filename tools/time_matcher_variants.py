@@ -3,7 +3,7 @@
 the top-2 kernel alone (HIP events on the launch stream) for one n x n pair.
     python tools/time_matcher_variants.py [n] [desc_bytes]
 Variants are values of tune knob 0: 1 = popcount (LDS tile, one query per lane),
-9 / 10 / 12 = matrix-core kernel with 1 / 2 / 4 query groups per wave."""
+9 / 10 = matrix-core kernel with 1 / 2 query groups per wave."""
 import ctypes as C
 import os
 import sys
@@ -24,7 +24,7 @@ out = (torch.empty((n, 2), dtype=torch.int32, device=q.device),
        torch.empty((n, 2), dtype=torch.int32, device=q.device),
        torch.empty(n, dtype=torch.uint8, device=q.device))
 tune = _lib.lib.slamhip_tune
-configs = [(1, 0)] + [(v, s) for v in (9, 10, 12) for s in (0, 4, 8, 16, 32, 64)]
+configs = [(1, 0)] + [(v, s) for v in (9, 10) for s in (0, 8, 16, 32)]
 ref = None
 best = {}
 for rnd in range(3):
