@@ -22,6 +22,7 @@ import torch
 from ... import _lib
 from ..._lib import lib, check, FrontendArgs
 from ... import kernels
+from .feature_cache import PackedFrames
 
 Frame = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]
 
@@ -70,6 +71,7 @@ class FrontendInputs:
     kp_right: torch.Tensor
     des_left: torch.Tensor
     des_right: torch.Tensor
+    host: Optional[object] = None     # the PackedFrames the inputs came from, if they did
 
     @property
     def desc_bytes(self) -> int:
@@ -81,18 +83,48 @@ class FrontendResult:
         self.inputs, self.W, self.t = inputs, W, t
         self.frame_cross_check = False
         self._host = None
+        self._pending = None
 
-    def to_host(self) -> dict:
-        """All result arrays as NumPy arrays.  They are copied through page-locked
+    # gathers of the inputs by the stereo match indices: two thirds of the result bytes, and
+    # a host that still holds the inputs (PackedFrames) can redo them itself when asked
+    _GATHERS = ("st_desc", "st_pix_left", "st_pix_right")
+
+    def to_host(self, gathers: Optional[bool] = None) -> dict:
+        """The result arrays as NumPy arrays.  They are copied through page-locked
         buffers (several times the rate of pageable copies) on the current stream, one
-        synchronisation for all of them; the arrays keep their buffers alive."""
-        if self._host is None:
-            pinned = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in self.t.items()}
-            for k, v in self.t.items():
-                pinned[k].copy_(v, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            self._host = {k: v.numpy() for k, v in pinned.items()}
+        synchronisation for all of them; the arrays keep their buffers alive.
+        `gathers`: also copy the inlier descriptors and pixels (rows of the inputs gathered
+        by the stereo matches); default: only when the inputs did not come from host
+        arrays this object can gather from itself (`frame()` does either way)."""
+        self.to_host_async(gathers)
+        if self._pending is not None:
+            ev, pinned = self._pending
+            ev.synchronize()
+            self._host = dict(self._host or {}, **{k: v.numpy() for k, v in pinned.items()})
+            self._pending = None
         return self._host
+
+    def to_host_async(self, gathers: Optional[bool] = None) -> None:
+        """Starts the copies of to_host() on the current stream and returns; the next
+        to_host() waits for them."""
+        if gathers is None:
+            gathers = self.inputs.host is None
+        have = set(self._host or {})
+        if self._pending is not None:
+            have |= set(self._pending[1])
+        want = [k for k in self.t if (gathers or k not in self._GATHERS) and k not in have]
+        if not want:
+            return
+        if self._pending is not None:       # a second request before the first was collected
+            ev, pinned = self._pending
+            ev.synchronize()
+            self._host = dict(self._host or {}, **{k: v.numpy() for k, v in pinned.items()})
+        pinned = {k: torch.empty(self.t[k].shape, dtype=self.t[k].dtype, pin_memory=True) for k in want}
+        for k, v in pinned.items():
+            v.copy_(self.t[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._pending = (ev, pinned)
 
     # ------------------------------------------------------------ per-frame views
     def frame(self, f: int) -> dict:
@@ -100,8 +132,14 @@ class FrontendResult:
         b = int(self.inputs.off_left[f])
         m = int(h["st_count"][f])
         sl = slice(b, b + m)
-        desc = h["st_desc"].reshape(-1, self.W)[sl].view(np.uint8)[:, :self.inputs.desc_bytes]
-        pl, pr = h["st_pix_left"].reshape(-1, 2)[sl], h["st_pix_right"].reshape(-1, 2)[sl]
+        if "st_desc" in h:
+            desc = h["st_desc"].reshape(-1, self.W)[sl].view(np.uint8)[:, :self.inputs.desc_bytes]
+            pl, pr = h["st_pix_left"].reshape(-1, 2)[sl], h["st_pix_right"].reshape(-1, 2)[sl]
+        else:           # the same rows taken from the host's own copy of the inputs
+            src = self.inputs.host
+            li = b + h["st_left"][sl].astype(np.int64)
+            ri = int(self.inputs.off_right[f]) + h["st_right"][sl].astype(np.int64)
+            desc, pl, pr = src.des_left[li], src.kp_left[li], src.kp_right[ri]
         return {
             "left_idx": h["st_left"][sl], "right_idx": h["st_right"][sl], "dist": h["st_dist"][sl],
             "xyz": h["st_xyz"].reshape(-1, 3)[sl], "pix_left": pl, "pix_right": pr,
@@ -133,6 +171,30 @@ class FrontendResult:
         return self.to_host()["pose_refined"].reshape(-1, 3, 4).copy()
 
 
+class ChunkedResult:
+    """Results of a sequence processed in chunks of consecutive pairs (TrackingFrontend.run_chunked):
+    frame(f) / pair(p) / relative_Rts() as on FrontendResult, answered by the chunk that owns
+    the frame or pair."""
+
+    def __init__(self, n_frames: int, chunk_pairs: int, chunks):
+        self.n_frames, self.chunk_pairs, self.chunks = n_frames, chunk_pairs, chunks
+
+    def to_host(self):
+        return [c.to_host() for c in self.chunks]
+
+    def frame(self, f: int) -> dict:
+        k = min(f // self.chunk_pairs, len(self.chunks) - 1)
+        return self.chunks[k].frame(f - k * self.chunk_pairs)
+
+    def pair(self, p: int) -> dict:
+        k = min(p // self.chunk_pairs, len(self.chunks) - 1)
+        return self.chunks[k].pair(p - k * self.chunk_pairs)
+
+    def relative_Rts(self) -> np.ndarray:
+        out = [c.to_host()["pose_refined"].reshape(-1, 3, 4)[:c.inputs.n_frames - 1] for c in self.chunks]
+        return np.concatenate(out) if out else np.zeros((0, 3, 4))
+
+
 class TrackingFrontend:
     """Parameters follow the reference's defaults: disparity_min / pixel_thresh
     (run_slam.py:31-32; pixel_thresh is shared by the stereo filter and the PnP
@@ -153,7 +215,18 @@ class TrackingFrontend:
 
     # ------------------------------------------------------------------ staging
     @staticmethod
-    def upload(frames: Sequence[Frame]) -> FrontendInputs:
+    def upload(frames) -> FrontendInputs:
+        """Frames -> device.  A list of per-frame tuples is concatenated into page-locked
+        staging buffers first; a PackedFrames (already concatenated; page-locked after
+        pin()) goes over as it is, four asynchronous copies."""
+        if isinstance(frames, PackedFrames):
+            if len(frames) < 1:
+                raise ValueError("need at least one frame")
+            dev = kernels.to_device
+            d_off_l, d_off_r = dev(frames.off_left, torch.int32), dev(frames.off_right, torch.int32)
+            kl, kr, dl, dr = (t.to(d_off_l.device, non_blocking=True) for t in frames.tensors())
+            return FrontendInputs(len(frames), frames.off_left, frames.off_right, d_off_l, d_off_r,
+                                  kl, kr, dl, dr, host=frames)
         if len(frames) < 1:
             raise ValueError("need at least one frame")
         nl = [len(f[0]) for f in frames]
@@ -185,6 +258,61 @@ class TrackingFrontend:
         _staging_mark()
         return inputs
 
+    # ------------------------------------------------------------------ chunks
+    def run_chunked(self, packed: PackedFrames, chunk_pairs: int = 128, samples: Optional[np.ndarray] = None,
+                    to_host: bool = True) -> ChunkedResult:
+        """A sequence held in (page-locked) host memory in chunks of `chunk_pairs` consecutive
+        pairs, three stages in flight: while the pass over chunk k runs on the current stream,
+        the features of chunk k+1 go host-to-device on a second stream and the results of
+        chunk k-1 device-to-host on a third.  Consecutive chunks share one frame (pair p needs
+        frames p and p+1; its stereo stage is done twice).  Same results as one run() over
+        the whole sequence: the device sampler keys pair p by its index in the sequence."""
+        F = len(packed)
+        if F < 1:
+            raise ValueError("need at least one frame")
+        chunk_pairs = max(1, int(chunk_pairs))
+        starts = list(range(0, max(F - 1, 1), chunk_pairs))
+        main = torch.cuda.current_stream()
+        s_in, s_out = self._side_streams()
+        s_in.wait_stream(main)
+        s_out.wait_stream(main)
+
+        def stage_in(k):
+            a = starts[k]
+            b = min(a + chunk_pairs, F - 1)
+            with torch.cuda.stream(s_in):
+                inp = self.upload(packed[a:b + 1])
+                ev = torch.cuda.Event()
+                ev.record(s_in)
+            return inp, ev
+
+        results = []
+        nxt = stage_in(0)
+        for k, a in enumerate(starts):
+            inp, ev = nxt
+            if k + 1 < len(starts):
+                nxt = stage_in(k + 1)
+            main.wait_event(ev)
+            smp = None if samples is None else samples[a:a + inp.n_frames - 1]
+            res = self.run(inp, samples=smp, first_pair=a)
+            results.append(res)
+            if to_host:
+                done = torch.cuda.Event()
+                done.record(main)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(done)
+                    res.to_host_async()
+        main.wait_stream(s_in)      # the inputs' memory may be reused only after their copies
+        out = ChunkedResult(F, chunk_pairs, results)
+        if to_host:
+            out.to_host()
+        return out
+
+    def _side_streams(self):
+        if getattr(self, "_streams", None) is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        return self._streams
+
     # ---------------------------------------------------------------------- run
     def run(self, frames_or_inputs, samples: Optional[np.ndarray] = None,
             first_pair: int = 0) -> FrontendResult:
@@ -192,6 +320,8 @@ class TrackingFrontend:
         device sampler keys pair p's samples by (seed, first_pair + p), so batches and
         shards of a sequence draw the samples of the uncut run."""
         inp = frames_or_inputs if isinstance(frames_or_inputs, FrontendInputs) else self.upload(frames_or_inputs)
+        if inp.kp_left.dtype != torch.float32 or inp.des_left.dtype != torch.uint8 or inp.des_left.dim() != 2:
+            raise ValueError("keypoints must be float32 (n, 2) and descriptors uint8 (n, D)")
         F = inp.n_frames
         NL, NR = int(inp.off_left[-1]), int(inp.off_right[-1])
         D = inp.desc_bytes

@@ -73,3 +73,29 @@ def test_extractor_script_says_what_it_needs_without_opencv(tmp_path):
     spec.loader.exec_module(mod)
     with pytest.raises(SystemExit, match="OpenCV"):
         mod.main(["--data", str(tmp_path), "--out", str(tmp_path / "cache")])
+
+
+def test_packed_frames_roundtrip_slices_and_file(tmp_path):
+    """One array set + offsets holds what the per-frame tuples hold: indexing gives the frames
+    back, a slice is a PackedFrames of that frame range with re-based offsets, empty images are
+    kept, and save / load keep everything."""
+    from slam_amd.backend.tracking.feature_cache import PackedFrames
+    rng = np.random.default_rng(4)
+    frames = [_frame(rng, nl, nr) for nl, nr in [(5, 6), (0, 3), (7, 0), (4, 4)]]
+    p = PackedFrames.from_frames(frames)
+    assert len(p) == 4 and p.off_left.tolist() == [0, 5, 5, 12, 16] and p.off_right.tolist() == [0, 6, 9, 9, 13]
+    for i, f in enumerate(frames):
+        for a, b in zip(p[i], f):
+            np.testing.assert_array_equal(a, b)
+    q = p[1:4]
+    assert len(q) == 3 and q.off_left.tolist() == [0, 0, 7, 11]
+    for a, b in zip(q[2], frames[3]):
+        np.testing.assert_array_equal(a, b)
+    assert len(p[2:2]) == 0
+    r = PackedFrames.load(p.save(str(tmp_path / "seq.npz")))
+    for name in ("kp_left", "kp_right", "des_left", "des_right", "off_left", "off_right"):
+        np.testing.assert_array_equal(getattr(r, name), getattr(p, name))
+    with pytest.raises(ValueError):
+        PackedFrames(p.kp_left[:3], p.kp_right, p.des_left, p.des_right, p.off_left, p.off_right)
+    with pytest.raises(ValueError):
+        p[0:4:2]

@@ -495,3 +495,36 @@ def test_front_end_with_other_descriptor_widths(nbytes):
             np.testing.assert_array_equal(got[k], ref[k], err_msg=f"pair {p} {k}")
         assert (got["mask"] != ref["mask"]).sum() <= 1 or got["best_index"] != ref["best_index"]
         assert got["mask"].mean() > 0.25
+
+
+def test_packed_frames_and_chunked_run_equal_the_plain_run():
+    """The same sequence handed over as per-frame tuples, as one page-locked PackedFrames, and
+    in overlapped chunks (one pass, chunks of 3 and of 1 pair): identical stereo and temporal
+    results, poses included (the device sampler is keyed by the pair's index in the sequence);
+    without a device copy of the gathered descriptors / pixels, frame() takes the same rows
+    from the host's own arrays."""
+    from slam_amd.backend.tracking.feature_cache import PackedFrames
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam, seq, frames = _sequence(8, 500, seed=21)
+    frames[3] = (frames[3][0][:200], frames[3][1][:310], frames[3][2][:200], frames[3][3][:310])
+    fe = TrackingFrontend(cam, n_iter_max=300, seed=4)
+    ref = fe.run(frames)
+    packed = PackedFrames.from_frames(frames).pin()
+    assert packed.is_pinned
+    one = fe.run(packed)
+    assert "st_desc" not in one.to_host() and "st_desc" in one.to_host(gathers=True)
+    light = fe.run(packed)                       # frame() from the host arrays only
+    for chunked in (fe.run_chunked(packed, chunk_pairs=3), fe.run_chunked(packed, chunk_pairs=1),
+                    fe.run_chunked(packed, chunk_pairs=100)):
+        for f in range(len(frames)):
+            a, b, c, d = ref.frame(f), one.frame(f), chunked.frame(f), light.frame(f)
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} frame {f}")
+                np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} frame {f} (chunked)")
+                np.testing.assert_array_equal(a[k], d[k], err_msg=f"{k} frame {f} (host gather)")
+        for p in range(len(frames) - 1):
+            a, b, c = ref.pair(p), one.pair(p), chunked.pair(p)
+            for k in a:
+                np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} pair {p}")
+                np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} pair {p} (chunked)")
+        np.testing.assert_array_equal(chunked.relative_Rts(), ref.relative_Rts())

@@ -1,0 +1,183 @@
+"""The two full-size workloads behind an assertion: 500 frames x 1500 features through the
+batched front-end, and all pairs of 270 keyframes through the loop-closure pair verification.
+Properties on every frame / pair, the C/OpenMP restatement of the front-end on the whole
+sequence with the same idx4 samples, the NumPy restatement on a few sampled pairs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import frontend_c as fc
+from oracle import pipeline_oracle as po
+from oracle import slam_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(cam, n_frames, n_features, seed, step=1, clutter=0.6):
+    from slam_amd.utils.synth import StereoSequence
+    seq = StereoSequence(cam, n_frames=n_frames * step, n_features=n_features, seed=seed, clutter=clutter)
+    frames = []
+    for k in range(n_frames):
+        f = seq.frame(k * step)
+        frames.append((f.kp_left, f.kp_right, f.des_left, f.des_right))
+    return seq, frames
+
+
+def _distinct_samples(rng, n, n_iter):
+    """(n_iter, 4) distinct indices below n per row (n >= 4)."""
+    s = rng.integers(0, n, (n_iter, 4))
+    for _ in range(64):
+        srt = np.sort(s, axis=1)
+        dup = (srt[:, 1:] == srt[:, :-1]).any(axis=1)
+        if not dup.any():
+            break
+        s[dup] = rng.integers(0, n, (int(dup.sum()), 4))
+    return s.astype(np.int32)
+
+
+def _assert_rigid(Rt, tol=1e-9):
+    R = Rt[..., :3]
+    err = np.abs(R @ np.swapaxes(R, -1, -2) - np.eye(3)).max()
+    assert err < tol, err
+    assert np.all(np.linalg.det(R) > 0.999)
+
+
+def test_500_frames_of_1500_features():
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam = CameraModel.kitti_like()
+    F, n_iter = 500, 2500
+    seq, frames = _frames(cam, F, 1500, seed=100)
+    fe = TrackingFrontend(cam, n_iter_max=n_iter)
+    inputs = fe.upload(frames)
+    st_count = TrackingFrontend(cam, n_iter_max=1).run(inputs).to_host()["st_count"][:F].copy()
+    rng = np.random.default_rng(9)
+    samples = np.zeros((F - 1, n_iter, 4), np.int32)
+    for p in range(F - 1):
+        if st_count[p] >= 4:
+            samples[p] = _distinct_samples(rng, int(st_count[p]), n_iter)
+    res = fe.run(inputs, samples=samples)
+    h = {k: v.copy() for k, v in res.to_host().items()}
+    again = fe.run(inputs, samples=samples).to_host()
+    info = h["ransac_info"].reshape(-1, 8)[:F - 1]
+    off = inputs.off_left
+    # run-to-run determinism: the arrays that start at zero whole, the others over the rows in use
+    for k in ("st_count", "ransac_info", "pose_ransac", "pose_refined", "tm_mask", "st_desc"):
+        np.testing.assert_array_equal(h[k], again[k], err_msg=k)
+    used_st = np.concatenate([np.arange(off[f], off[f] + h["st_count"][f]) for f in range(F)])
+    used_tm = np.concatenate([np.arange(off[p], off[p] + info[p, 5]) for p in range(F - 1)])
+    for k, rows, w in (("st_left", used_st, 1), ("st_right", used_st, 1), ("st_dist", used_st, 1),
+                       ("st_xyz", used_st, 3), ("st_pix_left", used_st, 2), ("st_pix_right", used_st, 2),
+                       ("tm_query", used_tm, 1), ("tm_train", used_tm, 1), ("tm_dist", used_tm, 1)):
+        np.testing.assert_array_equal(h[k].reshape(-1, w)[rows], again[k].reshape(-1, w)[rows], err_msg=k)
+    assert (h["st_count"][:F] == st_count).all() and st_count.min() > 400
+    for f in range(F):
+        fr = res.frame(f)
+        n = len(fr["left_idx"])
+        assert len(np.unique(fr["left_idx"])) == n and fr["left_idx"].max() < 1500    # a sorted subset of the queries
+        assert (np.diff(fr["dist"]) >= 0).all()
+        assert np.isfinite(fr["xyz"]).all() and (fr["xyz"][:, 2] > 0).all()
+    assert (info[:, 2] <= n_iter).all() and (info[:, 2] >= 1).all()
+    assert (info[:, 5] == st_count[:-1]).all()                    # one match per stereo inlier of the first frame
+    assert (info[:, 4] == 0).all()
+    for p in range(F - 1):
+        s = slice(off[p], off[p] + info[p, 5])
+        assert info[p, 1] == h["tm_mask"][s].sum(), p             # count == mask sum
+        assert (np.diff(h["tm_dist"][s]) >= 0).all()
+        assert h["tm_train"][s].max() < st_count[p + 1]
+    _assert_rigid(h["pose_ransac"].reshape(-1, 3, 4)[:F - 1])
+    _assert_rigid(h["pose_refined"].reshape(-1, 3, 4)[:F - 1])
+    truth_err = max(np.abs(res.pair(p)["Rt"][:, 3] - seq.relative_pose(p + 1)[:, 3]).max() for p in range(F - 1))
+    assert truth_err < 0.05, truth_err
+
+    # the C/OpenMP restatement over the whole sequence, same samples
+    c = fc.frontend_run(cam, frames, samples=samples, n_iter_max=n_iter)
+    np.testing.assert_array_equal(c["st_count"][:F], st_count)
+    for key_c, key_d in (("st_left", "st_left"), ("st_right", "st_right"), ("st_dist", "st_dist"),
+                         ("tm_q", "tm_query"), ("tm_t", "tm_train"), ("tm_d", "tm_dist")):
+        cnt = st_count if key_c.startswith("st") else c["tm_count"]
+        for f in range(F if key_c.startswith("st") else F - 1):
+            s = slice(off[f], off[f] + cnt[f])
+            np.testing.assert_array_equal(h[key_d][s], c[key_c][s], err_msg=f"{key_c} frame {f}")
+    xyz_d, xyz_c = h["st_xyz"].reshape(-1, 3), c["st_xyz"]
+    for f in range(0, F, 7):
+        s = slice(off[f], off[f] + st_count[f])
+        assert (np.abs(xyz_d[s] - xyz_c[s]) <= 1e-4 * np.abs(xyz_c[s]).max(axis=1, keepdims=True)).all()
+    same = info[:, 0] == c["info"][:F - 1, 0]
+    assert same.mean() > 0.9, same.mean()          # same winner (root-finder rounding aside)
+    for p in np.flatnonzero(same):
+        s = slice(off[p], off[p] + info[p, 5])
+        assert info[p, 2] == c["info"][p, 2], p                   # same number of iterations
+        assert (h["tm_mask"][s] != c["mask"][s]).sum() <= 1
+        assert np.abs(h["pose_refined"].reshape(-1, 3, 4)[p] - c["Rt"][p]).max() < 1e-5
+
+    # the NumPy restatement, frame at a time, on a few pairs
+    for p in (0, 123, 250, 498):
+        a, b = po.stereo_stage(cam, frames[p]), po.stereo_stage(cam, frames[p + 1])
+        ref = po.temporal_stage(cam, a, b, samples=samples[p], n_iter_max=n_iter)
+        got = res.pair(p)
+        np.testing.assert_array_equal(got["query_idx"], ref["query_idx"])
+        np.testing.assert_array_equal(got["train_idx"], ref["train_idx"])
+        eL, eR = so.hypothesis_errors(cam.K, cam.M_right, got["Rt_ransac"], ref["X_corr"], ref["pix_L"], ref["pix_R"])
+        bad = np.flatnonzero(((eL <= 4.0) & (eR <= 4.0)) != got["mask"])
+        assert all(min(abs(eL[i] - 4.0), abs(eR[i] - 4.0)) < 1e-6 for i in bad)
+        if got["best_index"] == ref["best_index"]:
+            assert got["iterations"] == ref["iterations"]
+
+
+def test_all_pairs_of_270_keyframes():
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam = CameraModel.kitti_like()
+    KF = 270
+    seq, frames = _frames(cam, KF, 1500, seed=7, step=17)
+    st = TrackingFrontend(cam, n_iter_max=1).run(frames)
+    keyframes = [(st.frame(k)["links"], st.frame(k)["inlier_des_left"]) for k in range(KF)]
+    pairs = np.array([(i, n) for n in range(KF) for i in range(n)], dtype=np.int64)
+    assert len(pairs) == 36315
+    ver = PairVerifier(cam, seed=2).set_keyframes(keyframes)
+    res = ver.verify(pairs)
+    keys = ("ok", "n_matches", "n_inliers", "iterations", "Rt", "Rt_ransac", "out_off")
+    first = {k: np.array(res[k]).copy() for k in keys}
+    vm = res.verified_matches()
+    res2 = ver.verify(pairs)
+    for k in keys:                                                 # run-to-run determinism
+        np.testing.assert_array_equal(first[k], np.array(res2[k]), err_msg=k)
+    ok = first["ok"].astype(bool)
+    nq = np.array([len(k[0]) for k in keyframes])
+    assert (first["n_matches"] == nq[pairs[:, 0]]).all()          # one match per row of the candidate keyframe
+    assert (np.diff(first["out_off"]) == first["n_matches"]).all()
+    assert (first["iterations"] <= ver.n_iter_max).all()
+    assert (first["n_inliers"][ok] >= ver.min_inliers).all()
+    assert 10 < ok.sum() < 2000                                    # neighbours along the track verify, the rest does not
+    assert (pairs[ok, 1] - pairs[ok, 0]).max() <= 3
+    _assert_rigid(first["Rt"][ok])
+    assert vm["pairs"].tolist() == np.flatnonzero(ok).tolist()
+    for k, p in enumerate(vm["pairs"]):
+        m = vm["mask"][int(vm["off"][k]):int(vm["off"][k + 1])]
+        assert len(m) == first["n_matches"][p] and m.sum() == first["n_inliers"][p]
+
+    def knn2(q, t):
+        return so.hamming_knn2(np.ascontiguousarray(q), np.ascontiguousarray(t))
+    rng = np.random.default_rng(1)
+    sample = list(np.flatnonzero(ok)[:: max(1, ok.sum() // 5)][:5]) + list(rng.choice(np.flatnonzero(~ok), 5, replace=False))
+    for p in sample:
+        i, n = pairs[p]
+        ref = po.consensus_pnp_match(cam, keyframes[i], keyframes[n], rng=np.random.default_rng(int(p)), knn2=knn2)
+        one = res.pair_matches(int(p))
+        np.testing.assert_array_equal(one["query_idx"], ref["query_idx"], err_msg=f"pair {p}")
+        np.testing.assert_array_equal(one["train_idx"], ref["train_idx"])
+        np.testing.assert_array_equal(one["dist"], ref["dist"])
+        if bool(ok[p]) != bool(ref["ok"]):
+            # other random samples: the two may only disagree on a pair whose consensus set is
+            # about as large as the gate (min_inliers_loop)
+            assert abs(int(first["n_inliers"][p]) - ver.min_inliers) <= 20 and \
+                abs(int(ref.get("best_count", 0)) - ver.min_inliers) <= 20, (p, first["n_inliers"][p], ref.get("best_count"))
+            continue
+        if ok[p]:
+            eL, eR = so.hypothesis_errors(cam.K, cam.M_right, first["Rt_ransac"][p], ref["P3D"], ref["ptsL"], ref["ptsR"])
+            bad = np.flatnonzero(((eL <= 1.5) & (eR <= 1.5)) != one["mask"])
+            assert all(min(abs(eL[k] - 1.5), abs(eR[k] - 1.5)) < 1e-6 for k in bad)
+            # other random samples on ~60-80 supporters 14 m apart: the same motion, not the same digits
+            assert np.abs(first["Rt"][p] - ref["Rt"]).max() < 0.5
