@@ -62,7 +62,10 @@ const char *slamhip_strerror(int code);
  * hypotheses; identical results; set it before sizing a workspace), knob 5 = sort
  * algorithm (0 auto, 1 rank counting, 2 bitonic network where the segments fit it;
  * same order), knob 6 / 7 = matrix-core matcher: blocks a launch aims at / train rows
- * per block it does not exceed when blocks abound (0 = default).  Process-global; not
+ * per block it does not exceed when blocks abound (0 = default), knob 8 = where the
+ * matrix-core matcher folds its train splits (2, the default: inside the launch for small
+ * calls, a merge launch for large ones; 1: always inside; 0: always a merge launch; set it
+ * before sizing a workspace; same results).  Process-global; not
  * for use while other threads are inside the library. */
 int slamhip_tune(int knob, int value);
 

@@ -63,12 +63,16 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          bool best_only = false,    // best_only: second-best entries come back as -1
          int splits = 0);
 // Matrix-core matcher (hamming_mfma.hip): same arguments as the popcount kernel's launch.
-// W = packed dwords per row, G = groups of 32 queries per wave (1, 2, 4; 32-word rows: 1, 2).
+// W = packed dwords per row, G = groups of 32 queries per wave (1 or 2; 32-word rows: 1).
+// arrivals != nullptr (grid.x * grid.z counters, zero at launch) with more than one split: the
+// kernel folds the splits itself (the last block to arrive of each query block does) and
+// applies the ratio test when keep != nullptr; otherwise the splits go to `part` for the merge kernel.
 int mfma_max_split_rows(int W);    // train rows one block may scan (width of its row index)
 void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
                          const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
                          const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
-                         int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2);
+                         int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2,
+                         unsigned *arrivals = nullptr, double ratio = 0.0, uint8_t *keep = nullptr);
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,

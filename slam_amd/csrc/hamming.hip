@@ -217,11 +217,13 @@ SLAMHIP_DEFINE_SCAN8(scan_tile8_best, SLAMHIP_PUSH1_R)
 __global__ __launch_bounds__(256) void pack_rows_kernel(
     const uint8_t *__restrict__ src_a, int n_a, uint32_t *__restrict__ dst_a,
     const uint8_t *__restrict__ src_b, int n_b, uint32_t *__restrict__ dst_b, int desc_bytes,
-    int stride, int log2W) {
+    int stride, int log2W, unsigned *__restrict__ zero = nullptr, int n_zero = 0) {
   // one thread per four packed dwords (one 16-byte store); W is a power of two >= 8,
   // so row / word group come from shifts
   const int lq = log2W - 2;
   const unsigned gid = blockIdx.x * blockDim.x + threadIdx.x;
+  // the matcher's arrival counters start every call at zero
+  for (unsigned i = gid; i < (unsigned)n_zero; i += gridDim.x * blockDim.x) zero[i] = 0u;
   const unsigned total_a = (unsigned)n_a << lq;
   const unsigned total = total_a + ((unsigned)n_b << lq);
   if (gid >= total) return;
@@ -605,7 +607,8 @@ struct MatchPlan {
   bool use_lds;
   bool mfma;   // matrix-core kernel (hamming_mfma.hip); G = groups of 32 queries per wave
   int G;
-  size_t off_qp, off_tp, off_part, total;
+  size_t off_qp, off_tp, off_part, off_cnt, total;
+  bool fold_in_kernel;   // matrix-core kernel folds its splits itself (arrival counters at off_cnt)
 };
 
 // Optional per-launch timing of the dominant (top-2) kernel with HIP events
@@ -634,8 +637,9 @@ bool default_mfma() {
   return v != 0;
 }
 int g_force_splits = 0;
-int g_mfma_target_blocks = 1024;   // matrix-core kernel: blocks a launch aims at (knob 6)
+int g_mfma_target_blocks = 512;    // matrix-core kernel: blocks a launch aims at (knob 6)
 int g_mfma_rows_per_split = 1024;  // and train rows per block it does not exceed when blocks abound (knob 7)
+int g_fold_in_kernel = 2;  // knob 8: 0 = always the separate merge launch, 1 = never, 2 = by size
 int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
 int g_force_sort = 0;      // 0 auto, 1 rank counting, 2 bitonic network (where it fits)
 
@@ -678,11 +682,17 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
     p.threads = kThreads;
     p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128 * G);
     const long long base_blocks = (long long)p.qblocks * (n_pairs > 0 ? n_pairs : 1);
+    // Two blocks per CU when the queries alone do not give them, at most 16 splits and at
+    // least one 128-row stage per split (measured, one n x n pair of 61-byte rows: n = 2048
+    // 16 splits, 4096 16, 8192 16, 16384 8 are the fastest or within 2 % of it); and no
+    // block longer than ~1024 train rows, so that the last blocks of a ragged batch do not
+    // leave the chip idle for long.
     long long s = (g_mfma_target_blocks + base_blocks - 1) / base_blocks;
+    if (s > 16) s = 16;
+    const int by_rows = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, 128);
+    if (s > by_rows) s = by_rows;
     const long long by_grain = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, g_mfma_rows_per_split);
     if (s < by_grain) s = by_grain;
-    const int by_rows = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, 64);
-    if (s > by_rows) s = by_rows;
     if (pinned_splits > 0) s = pinned_splits;
     if (g_force_splits > 0) s = g_force_splits;
     const long long need = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, mfma_rows);
@@ -726,6 +736,19 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   if (!prepacked) o = slamhip_align_up(o + (size_t)nt_total * p.W * 4, 256);
   p.off_part = o;
   if (p.splits > 1) o = slamhip_align_up(o + (size_t)p.splits * (size_t)n_out * sizeof(uint2), 256);
+  // The matrix-core kernel folds its splits inside the launch when the call has a row
+  // packing launch in front of it (which clears the arrival counters): one launch less.
+  // Measured from a C++ loop (8192 x 8192 x 61 B, 16 splits): 20.2 us per call folded in the
+  // kernel against 19.5 with the merge launch (the fold is three dependent memory round trips
+  // at the kernel's tail, the merge launch overlaps with the next call's packing), but 9.6
+  // against 11.2 at 2048 x 2048, where the call is bound by its launches: small calls fold
+  // in the kernel (knob 8: 1 = always, 0 = never, 2 = by size).
+  const long long compares = (long long)(max_nq > 0 ? max_nq : 1) * (max_nt > 0 ? max_nt : 1) * (n_pairs > 0 ? n_pairs : 1);
+  const bool fold_wanted = g_fold_in_kernel == 1 || (g_fold_in_kernel == 2 && compares <= (8ll << 20));
+  p.fold_in_kernel = p.mfma && p.splits > 1 && !prepacked && fold_wanted;
+  p.off_cnt = o;
+  if (p.fold_in_kernel)
+    o = slamhip_align_up(o + (size_t)p.qblocks * (size_t)(n_pairs > 0 ? n_pairs : 1) * sizeof(unsigned), 256);
   p.total = o + 256;
   return p;
 }
@@ -769,6 +792,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   uint32_t *qp = (uint32_t *)(base + p.off_qp);
   uint32_t *tp = (uint32_t *)(base + p.off_tp);
   uint2 *part = (uint2 *)(base + p.off_part);
+  unsigned *arrivals = (unsigned *)(base + p.off_cnt);
 
   if (prepacked) {
     // rows are already W dwords each, 16-byte aligned
@@ -780,8 +804,9 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     const long long total = ((long long)nq_total + nt_total) * (p.W / 4);
     if (total >= (1ll << 31)) return SLAMHIP_EUNSUPPORTED;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks), dim3(256), 0, st, d_query, nq_total, qp,
-                       d_train, nt_total, tp, desc_bytes, row_stride, p.W == 8 ? 3 : (p.W == 16 ? 4 : 5));
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, d_query, nq_total, qp,
+                       d_train, nt_total, tp, desc_bytes, row_stride, p.W == 8 ? 3 : (p.W == 16 ? 4 : 5),
+                       p.fold_in_kernel ? arrivals : nullptr, p.fold_in_kernel ? p.qblocks * n_pairs : 0);
     SLAMHIP_CHECK_LAUNCH();
   }
 
@@ -803,7 +828,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
                                      nqs, nts, n_out_total, part, d_idx2, d_dist2)
   if (p.mfma) {
     slamhip_internal::launch_hamming_mfma(p.W, p.G, best_only, grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off,
-                                          d_t_cnt, d_out_off, nqs, nts, n_out_total, part, d_idx2, d_dist2);
+                                          d_t_cnt, d_out_off, nqs, nts, n_out_total, part, d_idx2, d_dist2,
+                                          p.fold_in_kernel ? arrivals : nullptr, ratio, d_keep);
   } else if (best_only && p.use_lds && p.Q == 1 && p.W <= 16) {
     if (p.threads == kThreads / 2) { if (p.W == 8) SLAMHIP_DISPATCH_BEST(8, kThreads / 2); else SLAMHIP_DISPATCH_BEST(16, kThreads / 2); }
     else                           { if (p.W == 8) SLAMHIP_DISPATCH_BEST(8, kThreads); else SLAMHIP_DISPATCH_BEST(16, kThreads); }
@@ -826,7 +852,9 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   if (ev) (void)hipEventRecord(ev->second, st);
   SLAMHIP_CHECK_LAUNCH();
 
-  if (p.splits > 1) {
+  if (p.fold_in_kernel) {
+    // folded and ratio-tested by the kernel itself
+  } else if (p.splits > 1) {
     if (p.splits >= 16)
       hipLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
                          0, st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
@@ -883,8 +911,9 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 3) g_force_threads = value;
   else if (knob == 4) slamhip_internal::g_ransac_mode = value;
   else if (knob == 5) g_force_sort = value;
-  else if (knob == 6) g_mfma_target_blocks = value > 0 ? value : 1024;
+  else if (knob == 6) g_mfma_target_blocks = value > 0 ? value : 512;
   else if (knob == 7) g_mfma_rows_per_split = value > 0 ? value : 1024;
+  else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
 }

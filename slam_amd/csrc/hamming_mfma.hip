@@ -127,7 +127,8 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
     const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
     const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
-    uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2) {
+    uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2,
+    unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep) {
   using GEO = Geo<W>;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
   constexpr int D = 32 * W;
@@ -393,8 +394,64 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
       idx2[2 * row + 1] = k2 == kNoKey ? -1 : (int32_t)(k2 & im);
       dist2[2 * row + 0] = k1 == kNoKey ? -1 : (int32_t)(k1 >> kKeyShift);
       dist2[2 * row + 1] = k2 == kNoKey ? -1 : (int32_t)(k2 >> kKeyShift);
-    } else {
+    } else if (arrivals == nullptr) {
       partial[(size_t)split * nq_total + row] = make_uint2(k1, k2);
+    } else {
+      // write-through store (sc1): visible to the block that folds the splits without a
+      // release of this compute die's L2
+      __hip_atomic_store(reinterpret_cast<unsigned long long *>(partial + (size_t)split * nq_total + row),
+                         (unsigned long long)k1 | ((unsigned long long)k2 << 32), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+
+  // ---- fold of the splits inside the launch: every block of a query block adds one to the
+  // query block's arrival count once its key pairs are written; the block whose add comes
+  // last reads all of them back (sc1 loads: past the vector L1) and writes the final result.
+  // The count is zero at launch (the row packing launch clears it) and the last block puts
+  // it back to zero.
+  if (arrivals != nullptr && n_splits > 1) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's key pairs have left
+    __syncthreads();                                      // ... and every other wave's of the block
+    int *const last_flag = reinterpret_cast<int *>(lds);  // the stage buffers are no longer read
+    unsigned *const cnt = arrivals + (size_t)pair * gridDim.x + blockIdx.x;
+    if (tid == 0) {
+      const unsigned before = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last_flag[0] = before == (unsigned)(n_splits - 1);
+    }
+    __syncthreads();
+    if (last_flag[0]) {
+      if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int q = tid; q < 128 * G; q += kThreads) {
+        if (qblk + q >= nq) continue;
+        const size_t row = (size_t)(o0 + qblk + q);
+        uint32_t m1 = kNoKey, m2 = kNoKey;                // smallest, second smallest key
+        for (int sp0 = 0; sp0 < n_splits; sp0 += 8) {     // eight loads in flight at a time
+          unsigned long long v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            v[j] = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(
+                                         partial + (size_t)min(sp0 + j, n_splits - 1) * nq_total + row),
+                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {                   // a split read twice changes nothing
+            const uint32_t a = (uint32_t)v[j], b = (uint32_t)(v[j] >> 32);   // a <= b within a split
+            // keys are unique (distance << 21 | train row), "none" is the largest value
+            if (a < m1) { m2 = min(m1, b); m1 = a; }
+            else if (a < m2 && a != m1) m2 = a;
+          }
+        }
+        const uint32_t im = (1u << kKeyShift) - 1u;
+        int2 oi, od;
+        oi.x = m1 == kNoKey ? -1 : (int32_t)(m1 & im);
+        oi.y = m2 == kNoKey ? -1 : (int32_t)(m2 & im);
+        od.x = m1 == kNoKey ? -1 : (int32_t)(m1 >> kKeyShift);
+        od.y = m2 == kNoKey ? -1 : (int32_t)(m2 >> kKeyShift);
+        reinterpret_cast<int2 *>(idx2)[row] = oi;
+        reinterpret_cast<int2 *>(dist2)[row] = od;
+        if (keep != nullptr)
+          keep[row] = (od.x >= 0 && od.y >= 0 && (double)od.x < ratio * (double)od.y) ? 1 : 0;
+      }
     }
   }
 #if (SLAMHIP_ABLATE & 64)
@@ -420,9 +477,10 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
 template <int W, int G, bool BEST>
 void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, const int32_t *q_off,
             const int32_t *q_cnt, const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off,
-            int nq, int nt, int nq_total, uint2 *part, int32_t *idx2, int32_t *dist2) {
+            int nq, int nt, int nq_total, uint2 *part, int32_t *idx2, int32_t *dist2, unsigned *arrivals,
+            double ratio, uint8_t *keep) {
   hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST>), grid, dim3(kThreads), 0, st, qp, tp, q_off, q_cnt,
-                     t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2);
+                     t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep);
 }
 
 }  // namespace
@@ -434,13 +492,14 @@ int mfma_max_split_rows(int W) { return W == 32 ? (1 << 12) : (1 << 13); }
 void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
                          const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
                          const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
-                         int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2) {
+                         int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2,
+                         unsigned *arrivals, double ratio, uint8_t *keep) {
 #define SLAMHIP_MFMA_CASE(WW, GG)                                                                    \
   if (W == WW && G == GG) {                                                                          \
     if (best) launch<WW, GG, true>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,    \
-                                   nq_total, (uint2 *)part, idx2, dist2);                            \
+                                   nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep);     \
     else launch<WW, GG, false>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,        \
-                               nq_total, (uint2 *)part, idx2, dist2);                                \
+                               nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep);         \
     return;                                                                                          \
   }
   SLAMHIP_MFMA_CASE(8, 1) SLAMHIP_MFMA_CASE(8, 2)

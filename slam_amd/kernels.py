@@ -118,6 +118,49 @@ def hamming_knn2_ratio(q, t, ratio: float, out=None):
     return idx2, dist2, keep
 
 
+class BoundRatioMatch:
+    """hamming_knn2_ratio with everything that does not change from call to call done once:
+    device tensors checked, outputs and workspace allocated, the C arguments converted.
+    Calling the object enqueues the matcher on the stream it was bound on and returns
+    (idx2, dist2, keep), the same tensors every time.  For loops that match into the same
+    buffers again and again (a tracker's per-frame call, a benchmark): the per-call host work
+    is one foreign call instead of the argument checking of the array-native wrapper."""
+
+    def __init__(self, q, t, ratio: float, out=None):
+        import ctypes as C
+        q, t = _desc_pair(q, t)
+        nq, nt = q.shape[0], t.shape[0]
+        if nq == 0 or nt == 0:
+            raise ValueError("bind needs non-empty descriptor sets")
+        d = q.shape[1]
+        if out is None:
+            out = (torch.empty((nq, 2), dtype=torch.int32, device=q.device),
+                   torch.empty((nq, 2), dtype=torch.int32, device=q.device),
+                   torch.empty(nq, dtype=torch.uint8, device=q.device))
+        idx2, dist2, keep = out
+        for o, shape, dt in ((idx2, (nq, 2), torch.int32), (dist2, (nq, 2), torch.int32), (keep, (nq,), torch.uint8)):
+            if tuple(o.shape) != shape or o.dtype != dt or not o.is_contiguous() or o.device != q.device:
+                raise ValueError("out must be contiguous device tensors on the descriptors' device: "
+                                 "(nq,2) int32, (nq,2) int32, (nq,) uint8")
+        need = lib.slamhip_hamming_knn2_workspace_bytes(nq, nt, 1, nq, nt, d)
+        if need == 0:
+            check(_lib.EUNSUPPORTED, "slamhip_hamming_knn2_workspace_bytes")
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)      # its own: not shared with other calls
+        self.out = out
+        self._keep = (q, t, ws)
+        self._fn = lib.slamhip_hamming_knn2_ratio
+        self._args = (C.c_void_p(q.data_ptr()), C.c_int(nq), C.c_void_p(t.data_ptr()), C.c_int(nt), C.c_int(d),
+                      C.c_int(d), C.c_double(float(ratio)), C.c_void_p(idx2.data_ptr()),
+                      C.c_void_p(dist2.data_ptr()), C.c_void_p(keep.data_ptr()), C.c_void_p(ws.data_ptr()),
+                      C.c_size_t(ws.numel()), C.c_void_p(_stream()))
+
+    def __call__(self):
+        rc = self._fn(*self._args)
+        if rc != 0:
+            check(rc, "slamhip_hamming_knn2_ratio")
+        return self.out
+
+
 def hamming_knn2_batched(q, t, q_off, t_off, max_nq: Optional[int] = None,
                          max_nt: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """n_pairs independent problems in one launch; offsets are (n_pairs+1,)

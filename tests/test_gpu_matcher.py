@@ -18,6 +18,7 @@ def _reset_tuning(request):
     yield
     _lib.lib.slamhip_tune(0, -1)
     _lib.lib.slamhip_tune(1, 0)
+    _lib.lib.slamhip_tune(8, 2)
 
 
 def _run(q, t):
@@ -369,3 +370,70 @@ def test_rows_at_any_alignment_and_stride(desc_bytes, stride, offset):
     assert rc == 0
     np.testing.assert_array_equal(idx2.cpu().numpy(), ref_i)
     np.testing.assert_array_equal(dist2.cpu().numpy(), ref_d)
+
+
+@pytest.mark.parametrize("splits", [0, 2, 7, 64])
+def test_splits_folded_inside_the_launch_equal_the_merge_launch(splits):
+    """The matrix-core kernel folds its train splits itself (the last block to arrive of each
+    query block reads the others' key pairs back; tune knob 8) or leaves them to a merge
+    launch: same results bit for bit, with many equal distances, on single pairs, on a ragged
+    batch with empty pairs, with the ratio test, and call after call in one workspace (the
+    arrival counters must be back at zero every time), sizes changing in between."""
+    from slam_amd import _lib, kernels
+    rng = np.random.default_rng(splits)
+    _lib.lib.slamhip_tune(0, 8)
+    _lib.lib.slamhip_tune(1, splits)
+    shapes = [(1, 1, 61), (700, 900, 61), (257, 4100, 32), (2049, 513, 61), (300, 8200, 61), (130, 513, 128),
+              (4096, 4096, 61)]
+    for rep in range(3):
+        for nq, nt, d in shapes:
+            q = rng.integers(0, 4, (nq, d), dtype=np.uint8)
+            t = rng.integers(0, 4, (nt, d), dtype=np.uint8)
+            out = {}
+            for fold in (1, 0):
+                _lib.lib.slamhip_tune(8, fold)
+                i, dd, k = kernels.hamming_knn2_ratio(q, t, 0.8)
+                torch.cuda.synchronize()
+                out[fold] = (i.cpu().numpy(), dd.cpu().numpy(), k.cpu().numpy())
+            for a, b in zip(out[1], out[0]):
+                np.testing.assert_array_equal(a, b, err_msg=f"{nq}x{nt}x{d} rep {rep}")
+            if nq * nt <= 700 * 900:
+                ei, ed = so.hamming_knn2(q, t)
+                np.testing.assert_array_equal(out[1][0], ei)
+                np.testing.assert_array_equal(out[1][1], ed)
+    sizes = [(610, 600), (0, 5), (131, 0), (257, 2640), (5, 1), (1300, 1290)]
+    qs = [rng.integers(0, 256, (a, 61), dtype=np.uint8) for a, _ in sizes]
+    ts = [rng.integers(0, 256, (b, 61), dtype=np.uint8) for _, b in sizes]
+    q_off = np.concatenate([[0], np.cumsum([len(x) for x in qs])]).astype(np.int32)
+    t_off = np.concatenate([[0], np.cumsum([len(x) for x in ts])]).astype(np.int32)
+    res = {}
+    for fold in (1, 0):
+        _lib.lib.slamhip_tune(8, fold)
+        bi, bd = kernels.hamming_knn2_batched(np.concatenate(qs), np.concatenate(ts), q_off, t_off)
+        res[fold] = (bi.cpu().numpy(), bd.cpu().numpy())
+    np.testing.assert_array_equal(res[1][0], res[0][0])
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+    for p in range(len(sizes)):
+        ei, ed = so.hamming_knn2(qs[p], ts[p])
+        np.testing.assert_array_equal(res[1][0][q_off[p]:q_off[p + 1]], ei, err_msg=f"pair {p}")
+        np.testing.assert_array_equal(res[1][1][q_off[p]:q_off[p + 1]], ed)
+
+
+def test_bound_call_equals_the_array_native_call():
+    """BoundRatioMatch (arguments checked and converted once) enqueues the same call: same
+    results as hamming_knn2_ratio, call after call, into the tensors it was given."""
+    from slam_amd import kernels
+    rng = np.random.default_rng(8)
+    q = rng.integers(0, 8, (900, 61), dtype=np.uint8)
+    t = rng.integers(0, 8, (1100, 61), dtype=np.uint8)
+    ei, ed, ek = (x.cpu().numpy() for x in kernels.hamming_knn2_ratio(q, t, 0.9))
+    bound = kernels.BoundRatioMatch(q, t, 0.9)
+    for _ in range(3):
+        i, d, k = bound()
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i.cpu().numpy(), ei)
+        np.testing.assert_array_equal(d.cpu().numpy(), ed)
+        np.testing.assert_array_equal(k.cpu().numpy(), ek)
+        i.zero_()
+    with pytest.raises(ValueError):
+        kernels.BoundRatioMatch(q, t, 0.9, out=(i, d, torch.empty(5, dtype=torch.uint8, device="cuda")))
