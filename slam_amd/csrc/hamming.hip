@@ -471,28 +471,29 @@ __global__ __launch_bounds__(256) void ratio_test_kernel(const int32_t *__restri
   keep[i] = (d.x >= 0 && d.y >= 0 && (double)d.x < ratio * (double)d.y) ? 1 : 0;
 }
 
-// crossCheck=True fold.  One thread per query row scans the train->query
-// result; nt is a few thousand, so the O(nq*nt) scan of 8-byte entries is a
-// small fraction of the distance work that produced it, and the ascending scan
-// gives the lowest-train-index tie rule for free.
-__global__ __launch_bounds__(256) void cross_check_kernel(const int32_t *__restrict__ t2q_idx2,
-                                                          const int32_t *__restrict__ t2q_dist2,
-                                                          int nt, int nq,
-                                                          int32_t *__restrict__ match_idx,
-                                                          int32_t *__restrict__ match_dist) {
-  const int qi = blockIdx.x * blockDim.x + threadIdx.x;
-  if (qi >= nq) return;
-  int best_t = -1, best_d = 0x7FFFFFFF;
-  for (int t = 0; t < nt; ++t) {
-    const int who = t2q_idx2[2 * t];  // wave-uniform address -> scalar load
-    const int d = t2q_dist2[2 * t];
-    if (who == qi && d < best_d) {
-      best_d = d;
-      best_t = t;
-    }
-  }
-  match_idx[qi] = best_t;
-  match_dist[qi] = best_t < 0 ? -1 : best_d;
+// crossCheck=True fold (single pair).  Every train row bids (distance, its own index)
+// for the query row it chose with one atomic minimum on a key per query row: a query
+// keeps the closest of the train rows that chose it, lowest train index on ties (the
+// fold of cv2's batchDistance with crossCheck) in O(nt + nq).  The keys live in
+// match_idx until they are decoded in place.
+__global__ __launch_bounds__(256) void cross_bid_one_kernel(const int32_t *__restrict__ t2q_idx2,
+                                                            const int32_t *__restrict__ t2q_dist2,
+                                                            int nt, int nq, uint32_t *__restrict__ bid) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nt) return;
+  const int who = t2q_idx2[2 * (size_t)t];
+  if (who < 0 || who >= nq) return;
+  const uint32_t d = (uint32_t)t2q_dist2[2 * (size_t)t];
+  atomicMin(&bid[who], (d << kKeyShift) | (uint32_t)t);
+}
+
+__global__ __launch_bounds__(256) void cross_decode_one_kernel(int nq, int32_t *__restrict__ match_idx,
+                                                               int32_t *__restrict__ match_dist) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t b = (uint32_t)match_idx[i];
+  match_idx[i] = b == kNoKey ? -1 : (int32_t)(b & kIdxMask);
+  match_dist[i] = b == kNoKey ? -1 : (int32_t)(b >> kKeyShift);
 }
 
 // ---------------------------------------------------------------------------
@@ -504,11 +505,15 @@ __global__ __launch_bounds__(256) void cross_check_kernel(const int32_t *__restr
 // ---------------------------------------------------------------------------
 constexpr int kBitonicMax = 8192;
 
-__global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__restrict__ dist,
-                                                           int dist_stride, int n_single,
-                                                           const int32_t *__restrict__ off,
-                                                           const int32_t *__restrict__ cnt,
-                                                           int32_t *__restrict__ order, int lds_keys) {
+// T threads per block: 256 when there are segments enough to fill the chip with such blocks,
+// 1024 when there are few (a block's time is what the call takes then: 16 waves per segment
+// instead of 4).
+template <int T>
+__global__ __launch_bounds__(T) void bitonic_sort_kernel(const int32_t *__restrict__ dist,
+                                                         int dist_stride, int n_single,
+                                                         const int32_t *__restrict__ off,
+                                                         const int32_t *__restrict__ cnt,
+                                                         int32_t *__restrict__ order, int lds_keys) {
   extern __shared__ uint32_t skeys[];
   const int seg = blockIdx.x;
   int s0 = 0, n = n_single;
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__rest
   if (n <= 0 || n > lds_keys) return;
   int N = 1;
   while (N < n) N <<= 1;
-  for (int i = threadIdx.x; i < N; i += 256) {
+  for (int i = threadIdx.x; i < N; i += T) {
     uint32_t key = kNoKey;                  // padding sorts last
     if (i < n) {
       const int d = dist[(size_t)(s0 + i) * dist_stride];
@@ -532,7 +537,7 @@ __global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__rest
   __syncthreads();
   for (int k = 2; k <= N; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = threadIdx.x; t < (N >> 1); t += 256) {
+      for (int t = threadIdx.x; t < (N >> 1); t += T) {
         const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // t with a 0 inserted at bit log2(j)
         const int hi = lo | j;
         const uint32_t a = skeys[lo], b = skeys[hi];
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(256) void bitonic_sort_kernel(const int32_t *__rest
       __syncthreads();
     }
   }
-  for (int r = threadIdx.x; r < n; r += 256) order[s0 + r] = (int32_t)(skeys[r] & kIdxMask);
+  for (int r = threadIdx.x; r < n; r += T) order[s0 + r] = (int32_t)(skeys[r] & kIdxMask);
 }
 
 // ---------------------------------------------------------------------------
@@ -871,21 +876,24 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 }
 
 // Stable sort of every segment by (distance, index): LDS bitonic network (one block
-// per segment) when the segments fit it and there are enough of them to fill the
-// chip, rank counting (many blocks per segment) otherwise.
+// per segment; 1024 threads when the segments are few and long) when the segments fit
+// it, rank counting (many blocks per segment) for longer ones.
 void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int32_t *d_off,
                  const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order, hipStream_t st) {
-  // One block per segment pays once there are segments enough to keep many CUs busy
-  // (measured: 500 segments of 1500 rows 30 us against 60; 64 segments the other way
-  // round); fewer segments sort faster by rank counting over many blocks.
-  bool bitonic = max_n <= kBitonicMax && n_segments >= 128;
+  // Measured: 500 segments of 1500 rows 30 us by the network (256 threads) against 60 by
+  // rank counting; 60 segments of 2000-8000 rows: the front-end pass 0.91 ms with the
+  // 1024-thread network against 1.03 ms with rank counting.
+  bool bitonic = max_n <= kBitonicMax;
   if (g_force_sort == 1) bitonic = false;
-  if (g_force_sort == 2) bitonic = max_n <= kBitonicMax;
   if (bitonic) {
     int N = 1;
     while (N < max_n) N <<= 1;
-    hipLaunchKernelGGL(bitonic_sort_kernel, dim3(n_segments), dim3(256), (size_t)N * sizeof(uint32_t),
-                       st, d_dist, dist_stride, n_single, d_off, d_cnt, d_order, N);
+    if (n_segments >= 128 || N <= 1024)
+      hipLaunchKernelGGL(bitonic_sort_kernel<256>, dim3(n_segments), dim3(256), (size_t)N * sizeof(uint32_t),
+                         st, d_dist, dist_stride, n_single, d_off, d_cnt, d_order, N);
+    else
+      hipLaunchKernelGGL(bitonic_sort_kernel<1024>, dim3(n_segments), dim3(1024), (size_t)N * sizeof(uint32_t),
+                         st, d_dist, dist_stride, n_single, d_off, d_cnt, d_order, N);
   } else {
     const dim3 grid(slamhip_ceil_div(max_n, 256), n_segments);
     hipLaunchKernelGGL(rank_sort_kernel, grid, dim3(256), 0, st, d_dist, dist_stride, n_single, d_off,
@@ -1010,9 +1018,16 @@ int slamhip_cross_check(const int32_t *d_t2q_idx2, const int32_t *d_t2q_dist2, i
   if (nq == 0) return SLAMHIP_OK;
   if (!d_match_idx || !d_match_dist || (nt > 0 && (!d_t2q_idx2 || !d_t2q_dist2)))
     return SLAMHIP_EINVAL;
-  hipLaunchKernelGGL(cross_check_kernel, dim3(slamhip_ceil_div(nq, 256)), dim3(256), 0,
-                     (hipStream_t)stream, d_t2q_idx2, d_t2q_dist2, nt, nq, d_match_idx,
-                     d_match_dist);
+  if (nt > SLAMHIP_MAX_TRAIN_ROWS) return SLAMHIP_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(d_match_idx, 0xFF, (size_t)nq * sizeof(int32_t), st) != hipSuccess) return SLAMHIP_ELAUNCH;
+  if (nt > 0) {
+    hipLaunchKernelGGL(cross_bid_one_kernel, dim3(slamhip_ceil_div(nt, 256)), dim3(256), 0, st, d_t2q_idx2,
+                       d_t2q_dist2, nt, nq, (uint32_t *)d_match_idx);
+    SLAMHIP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(cross_decode_one_kernel, dim3(slamhip_ceil_div(nq, 256)), dim3(256), 0, st, nq,
+                     d_match_idx, d_match_dist);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

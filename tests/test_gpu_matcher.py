@@ -19,6 +19,7 @@ def _reset_tuning(request):
     _lib.lib.slamhip_tune(0, -1)
     _lib.lib.slamhip_tune(1, 0)
     _lib.lib.slamhip_tune(8, 2)
+    _lib.lib.slamhip_tune(5, 0)
 
 
 def _run(q, t):
@@ -277,8 +278,10 @@ def test_ratio_test_and_sort_and_cross_check():
     np.testing.assert_array_equal(md.cpu().numpy(), ed)
 
 
-def test_sort_large_and_segmented():
-    from slam_amd import kernels
+@pytest.mark.parametrize("force_sort", [0, 1])      # tune knob 5: 0 = auto (network where it fits), 1 = rank counting
+def test_sort_large_and_segmented(force_sort):
+    from slam_amd import _lib, kernels
+    _lib.lib.slamhip_tune(5, force_sort)
     rng = np.random.default_rng(4)
     d = rng.integers(0, 489, 9000).astype(np.int32)
     d[rng.random(9000) < 0.01] = -1
@@ -290,7 +293,7 @@ def test_sort_large_and_segmented():
     o = kernels.sort_by_distance(dd, off=off).cpu().numpy()
     for s in range(len(sizes)):
         np.testing.assert_array_equal(o[off[s]:off[s + 1]], so.sort_by_distance(dd[off[s]:off[s + 1]]))
-    # single segments (rank counting): powers of two and their neighbours, absent distances (-1)
+    # single segments (network with 1024 threads up to 8192 rows, rank counting beyond): powers of two and their neighbours, absent distances (-1)
     for n in (1, 2, 3, 255, 256, 257, 4097, 8191, 8192, 8193):
         d = rng.integers(0, 12, n).astype(np.int32)
         d[rng.random(n) < 0.05] = -1
