@@ -61,6 +61,60 @@ __global__ __launch_bounds__(256) void mix(int iters, float *sink, unsigned *cyc
   if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = (unsigned)(t1 - t0);
 }
 
+// the 16 x 16 x 128 shape of the same instruction family: 4 accumulator registers per lane, half the
+// multiply-adds per instruction; two accumulators, NFILL vector instructions behind each
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <int NFILL>
+__global__ __launch_bounds__(256) void mix16(int iters, float *sink, unsigned *cycles) {
+  v4f acc0 = {1, 2, 3, 4}, acc1 = {5, 6, 7, 8};
+  v4i fa = {(int)(0x2A2A2A2A ^ (threadIdx.x * 0x08080808u)), 0x22AA22AA, 0x2A2AA2A2, 0x22222222};
+  v4i fb = {0x2AA22AA2, (int)(0xA2A2A2A2 ^ (threadIdx.x * 0x80808080u)), 0x2222AAAA, 0x2A2A2A2A};
+  int sc = 127;
+  float x[8];
+  for (int j = 0; j < 8; ++j) x[j] = (float)(threadIdx.x + j);
+  float y = 3.0f, z = 5.0f;
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      if (half == 0)
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                     : "+v"(acc0) : "v"(fa), "v"(fb), "v"(sc));
+      else
+        asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3 op_sel_hi:[0,0,0] cbsz:4 blgp:4"
+                     : "+v"(acc1) : "v"(fa), "v"(fb), "v"(sc));
+#pragma unroll
+      for (int f = 0; f < NFILL; ++f) {
+        if (f & 1) asm volatile("v_max3_i32 %0, %0, %1, %2" : "+v"(x[f & 7]) : "v"(y), "v"(z));
+        else asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(x[f & 7]) : "v"(y), "v"(z));
+      }
+    }
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  float s = 0;
+  for (int i = 0; i < 4; ++i) s += acc0[i] + acc1[i];
+  for (int j = 0; j < 8; ++j) s += x[j];
+  if (s == 1.2345f) sink[0] = s;
+  if (threadIdx.x == 0 && blockIdx.x == 0) cycles[0] = (unsigned)(t1 - t0);
+}
+
+template <int NFILL>
+void run16(int blocks, int iters, float *sink, unsigned *cyc) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((mix16<NFILL>), dim3(blocks), dim3(256), 0, 0, iters, sink, cyc);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  hipLaunchKernelGGL((mix16<NFILL>), dim3(blocks), dim3(256), 0, 0, iters, sink, cyc);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  const double wps = blocks / 256.0;
+  printf("16x16x128  fillers/mfma %2d  waves/SIMD %.0f: %.3f ms = %.2f ns per instruction per SIMD = %.2f ns per 32x32x64 "
+         "equivalent\n", NFILL, wps, ms, ms * 1e6 / (2.0 * iters * wps), 2.0 * ms * 1e6 / (2.0 * iters * wps));
+}
+
 template <int NFILL, int NLDS, bool MFMA>
 void run(int blocks, int iters, float *sink, unsigned *cyc) {
   hipEvent_t e0, e1;
@@ -98,6 +152,10 @@ int main() {
     run<4, 0, false>(blocks, iters, sink, cyc);
     run<8, 0, false>(blocks, iters, sink, cyc);
     run<4, 1, false>(blocks, iters, sink, cyc);
+    run16<0>(blocks, 2 * iters, sink, cyc);
+    run16<1>(blocks, 2 * iters, sink, cyc);
+    run16<2>(blocks, 2 * iters, sink, cyc);
+    run16<3>(blocks, 2 * iters, sink, cyc);
   }
   return 0;
 }
