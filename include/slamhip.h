@@ -374,6 +374,29 @@ typedef struct slamhip_frontend_args {
 size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *args);
 int slamhip_frontend_batch(const slamhip_frontend_args *args, void *stream);
 
+/* Hand-over record of a finished batch: the rows in use of frames [frame_lo, frame_hi) and
+ * pairs [pair_lo, pair_hi) of the output arrays in `args`, compacted into one byte string on the
+ * device, so that a rank's share of a sequence reaches the rank that runs the back-end in one
+ * gather.  It holds what the reference passes to TrackingDB.add_frame per frame
+ * (backend/tracking/fill_database.py:231: links' pixels, inlier descriptors, temporal matches,
+ * inlier mask) and the poses the back-end reads (run_slam.py:88-89).
+ * Layout (little endian): int64 {frames, pairs, first_frame, first_pair, desc_bytes}, int64
+ * stereo counts[frames], int64 temporal counts[pairs]; flat over the frames: left index, right
+ * index, distance (int32), xyz (3 float32), left pixel, right pixel (2 float32 each), inlier
+ * descriptor (desc_bytes uint8); flat over the pairs: query index, train index, distance
+ * (int32), mask (uint8); per pair: refined pose, RANSAC pose (12 float64 each), the 8 int32 of
+ * d_ransac_info.  d_st_out_off / d_tm_out_off: device arrays of frames+1 / pairs+1 int64, the
+ * exclusive prefix sums of the owned frames' d_st_count and of the owned pairs' match counts
+ * (d_ransac_info[8 p + 5]), which the caller has read back to size the record: their last
+ * entries are stereo_rows / temporal_rows.  first_frame / first_pair: the caller's numbering of
+ * the first owned frame / pair in the whole sequence. */
+size_t slamhip_frontend_record_bytes(int n_frames, int n_pairs, long long stereo_rows, long long temporal_rows,
+                                     int desc_bytes);
+int slamhip_frontend_pack_record(const slamhip_frontend_args *args, int frame_lo, int frame_hi, int pair_lo,
+                                 int pair_hi, int64_t first_frame, int64_t first_pair,
+                                 const int64_t *d_st_out_off, const int64_t *d_tm_out_off, int64_t stereo_rows,
+                                 int64_t temporal_rows, uint8_t *d_record, size_t record_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Pair verification: LoopClosure.consensus_pnp_match                        */
 /* (backend/optimizers/loop_closure.py:167-235) for a LIST of                */

@@ -386,4 +386,5 @@ class TrackingFrontend:
         res = FrontendResult(inp, W, t)
         res.frame_cross_check = self.frame_cross_check      # selects the hand-over shape (db_adapter)
         res._keepalive = (d_samples,)
+        res.args = a            # the call's argument block (sharding packs hand-over records from it)
         return res

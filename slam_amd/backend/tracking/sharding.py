@@ -9,7 +9,7 @@ rank contributes ONE variable-length byte record - poses, links, inlier
 descriptors, temporal matches, masks: everything TrackingDB.add_frame and the
 bundle-adjustment back-end consume (run_slam.py:88-89) - to one all_gather
 (RCCL over xGMI with the nccl backend; gloo on CPU for tests).  The record is
-assembled on the device (row compaction by index gathers), so with nccl the
+assembled on the device (one row-compaction kernel), so with nccl the
 results never take a host hop before the collective.
 
 Record layout (little endian): int64 header [n_frames, n_pairs, first_frame,
@@ -61,49 +61,33 @@ def frames_for_rank(n_frames: int, world: int, rank: int):
     return lo, hi + 1, (lo, hi), (lo, own_hi)
 
 
-def _segment_rows(start: torch.Tensor, count: torch.Tensor) -> torch.Tensor:
-    """Row indices start[i] .. start[i]+count[i]-1 for every segment i, in order."""
-    count = count.to(torch.int64)
-    total = int(count.sum().item())
-    if total == 0:
-        return torch.zeros(0, dtype=torch.int64, device=start.device)
-    first = torch.cumsum(count, 0) - count
-    seg = torch.repeat_interleave(torch.arange(count.numel(), device=start.device), count,
-                                  output_size=total)
-    return start.to(torch.int64)[seg] + (torch.arange(total, device=start.device) - first[seg])
-
-
 def pack_result(res, frame_range: Tuple[int, int], pair_range: Tuple[int, int], first_frame: int,
                 first_pair: int) -> torch.Tensor:
     """Serialise the owned records of a FrontendResult into one uint8 tensor on
-    the result's device.  Ranges are local to the result's batch; first_frame /
-    first_pair are the global indices of the first owned frame / pair."""
-    t, inp = res.t, res.inputs
+    the result's device (one kernel: slamhip_frontend_pack_record).  Ranges are local
+    to the result's batch; first_frame / first_pair are the global indices of the
+    first owned frame / pair.  The owned frames' and pairs' row counts are read back
+    first (one small copy): they size the record."""
+    import ctypes as C
+    from ..._lib import lib, check
+    t = res.t
     dev = t["st_count"].device
-    D, W = inp.desc_bytes, res.W
     flo, fhi = frame_range
     plo, phi = pair_range
-    off = inp.d_off_left.to(torch.int64)
-    st_cnt = t["st_count"][flo:fhi].to(torch.int64)
-    info = t["ransac_info"].reshape(-1, 8)
-    tm_cnt = info[plo:phi, 5].to(torch.int64)
-    frows = _segment_rows(off[flo:fhi], st_cnt)
-    prows = _segment_rows(off[plo:phi], tm_cnt)
-    head = torch.tensor([fhi - flo, phi - plo, first_frame, first_pair, D], dtype=torch.int64, device=dev)
-
-    def b(x):
-        return x.contiguous().reshape(-1).view(torch.uint8)
-
-    parts = [b(head), b(st_cnt), b(tm_cnt)]
-    parts += [b(t["st_left"][frows]), b(t["st_right"][frows]), b(t["st_dist"][frows]),
-              b(t["st_xyz"].reshape(-1, 3)[frows]), b(t["st_pix_left"].reshape(-1, 2)[frows]),
-              b(t["st_pix_right"].reshape(-1, 2)[frows]),
-              b(t["st_desc"].reshape(-1, W).view(torch.uint8).reshape(-1, W * 4)[frows][:, :D])]
-    parts += [b(t["tm_query"][prows]), b(t["tm_train"][prows]), b(t["tm_dist"][prows]),
-              b(t["tm_mask"][prows])]
-    parts += [b(t["pose_refined"].reshape(-1, 12)[plo:phi]), b(t["pose_ransac"].reshape(-1, 12)[plo:phi]),
-              b(info[plo:phi])]
-    return torch.cat(parts)
+    nf, npairs = fhi - flo, phi - plo
+    counts = torch.cat([t["st_count"][flo:fhi], t["ransac_info"].reshape(-1, 8)[plo:phi, 5]]).cpu().numpy()
+    offs = np.zeros(nf + npairs + 2, np.int64)
+    np.cumsum(counts[:nf], out=offs[1:nf + 1])
+    np.cumsum(counts[nf:], out=offs[nf + 2:])
+    ns, nt = int(offs[nf]), int(offs[-1])
+    d_offs = torch.from_numpy(offs).to(dev)
+    nbytes = lib.slamhip_frontend_record_bytes(nf, npairs, ns, nt, res.inputs.desc_bytes)
+    blob = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    check(lib.slamhip_frontend_pack_record(C.byref(res.args), flo, fhi, plo, phi, first_frame, first_pair,
+                                           d_offs.data_ptr(), d_offs.data_ptr() + 8 * (nf + 1), ns, nt,
+                                           blob.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream),
+          "slamhip_frontend_pack_record")
+    return blob
 
 
 def pack_records(frames: Sequence[dict], pairs: Sequence[dict], first_frame: int, first_pair: int,

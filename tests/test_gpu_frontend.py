@@ -528,3 +528,33 @@ def test_packed_frames_and_chunked_run_equal_the_plain_run():
                 np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} pair {p}")
                 np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} pair {p} (chunked)")
         np.testing.assert_array_equal(chunked.relative_Rts(), ref.relative_Rts())
+
+
+@pytest.mark.parametrize("nbytes", [61, 32])
+def test_device_record_equals_the_host_record_byte_for_byte(nbytes):
+    """slamhip_frontend_pack_record (one kernel on the device) writes the same bytes as
+    sharding.pack_records builds on the host from the per-frame / per-pair views: whole batch,
+    an inner range of frames and pairs, and an empty range; merge_records reads it back."""
+    from slam_amd.backend.tracking import sharding
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam, seq, frames = _sequence(7, 450, seed=13)
+    if nbytes != 61:
+        frames = [(a, b, c[:, :nbytes].copy(), d[:, :nbytes].copy()) for a, b, c, d in frames]
+    frames[2] = (frames[2][0][:130], frames[2][1][:200], frames[2][2][:130], frames[2][3][:200])
+    res = TrackingFrontend(cam, n_iter_max=200, seed=2).run(frames)
+    for (flo, fhi), (plo, phi) in (((0, 7), (0, 6)), ((1, 4), (1, 3)), ((3, 3), (2, 2)), ((6, 7), (5, 5))):
+        blob = sharding.pack_result(res, (flo, fhi), (plo, phi), 100 + flo, 50 + plo).cpu().numpy()
+        fr = [res.frame(f) for f in range(flo, fhi)]
+        pr = []
+        for p in range(plo, phi):
+            d = res.pair(p)
+            d["n_iter_required"], d["domain_error"] = d["n_iter_required"], d["domain_error"]
+            pr.append(d)
+        want = sharding.pack_records(fr, pr, 100 + flo, 50 + plo, nbytes)
+        assert blob.shape == want.shape, (blob.shape, want.shape)
+        np.testing.assert_array_equal(blob, want)
+    whole = sharding.merge_records([sharding.pack_result(res, (0, 7), (0, 6), 0, 0).cpu().numpy()], 7)
+    for f in range(7):
+        a, c = whole.frame(f), res.frame(f)
+        for k in c:
+            np.testing.assert_array_equal(a[k], c[k], err_msg=k)

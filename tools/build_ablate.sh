@@ -6,5 +6,5 @@ set -e
 cd "$(dirname "$0")/../slam_amd/csrc"
 for N in "$@"; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-pass-failed -DSLAMHIP_ABLATE=$N $EXTRA -c hamming_mfma.hip -o /tmp/hamming_mfma_abl$N.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libslamhip_abl$N.so hamming.o /tmp/hamming_mfma_abl$N.o l2.o geometry.o ransac.o p3p.o refine.o pipeline.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../libslamhip_abl$N.so hamming.o /tmp/hamming_mfma_abl$N.o l2.o geometry.o ransac.o p3p.o refine.o pipeline.o records.o
 done
