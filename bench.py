@@ -242,6 +242,15 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
             np.abs(res.pair(p)["Rt"][:, 3] - seq.relative_pose(p + 1)[:, 3]).max() for p in range(0, F - 1, 25))),
         "roofline": roof,
     }
+    # accuracy of the chained trajectory against the synthetic truth (frame 0 = world), the
+    # figure the reference prints beside its trajectories (utils/utils.py:165-169)
+    from slam_amd.utils import utils as pu
+    est = pu.chain_rel_to_abs_w2c(res.relative_Rts())
+    gt = pu.relatives_from_abs_w2c_endpoints(np.stack(seq.poses[:F]), np.arange(F), np.zeros(F, int))[:, :3]
+    out["trajectory"] = {"rmse_m": pu.trajectory_rmse(est, gt), "path_m": 0.8 * (F - 1),
+                         "rot_err_deg_max": float(pu.rot_err_deg(est, gt).max()),
+                         "note": "PnP odometry alone (no bundle adjustment, no loop closure) on synthetic "
+                                 "KITTI-shaped frames with 0.5 px pixel noise"}
     # The same pass with the host on both sides: the sequence starts as one page-locked array
     # set in host memory (PackedFrames: what a feature cache hands over) and every result
     # array ends in host memory.  One pass, and the same in overlapped chunks (H2D of chunk

@@ -89,6 +89,15 @@ def test_500_frames_of_1500_features():
     _assert_rigid(h["pose_refined"].reshape(-1, 3, 4)[:F - 1])
     truth_err = max(np.abs(res.pair(p)["Rt"][:, 3] - seq.relative_pose(p + 1)[:, 3]).max() for p in range(F - 1))
     assert truth_err < 0.05, truth_err
+    # the chained trajectory (utils.chain_rel_to_abs_w2c, as run_slam.py chains relative_Rts)
+    # against the synthetic truth expressed in frame 0: 400 m of path, 0.5 px noise
+    from slam_amd.utils import utils as pu
+    est = pu.chain_rel_to_abs_w2c(res.relative_Rts())
+    gt = pu.relatives_from_abs_w2c_endpoints(np.stack(seq.poses[:F]), np.arange(F), np.zeros(F, int))[:, :3]
+    # odometry drift: measured 2.2 m RMSE (0.55 % of the path; the reference reports 27 m over
+    # KITTI-05's 2.2 km after PnP alone) and 2.2 degrees
+    assert pu.trajectory_rmse(est, gt) < 6.0, pu.trajectory_rmse(est, gt)
+    assert pu.rot_err_deg(est, gt).max() < 5.0
 
     # the C/OpenMP restatement over the whole sequence, same samples
     c = fc.frontend_run(cam, frames, samples=samples, n_iter_max=n_iter)
