@@ -63,12 +63,13 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          bool best_only = false,    // best_only: second-best entries come back as -1
          int splits = 0);
 // Matrix-core matcher (hamming_mfma.hip): same arguments as the popcount kernel's launch.
-// W = packed dwords per row, G = groups of 32 queries per wave (1 or 2; 32-word rows: 1).
+// W = packed dwords per row, G = groups of 32 queries per wave (1 or 2; 32-word rows: 1),
+// NW = waves per block (4, or 8 with G = 2 and rows of at most 16 words).
 // arrivals != nullptr (grid.x * grid.z counters, zero at launch) with more than one split: the
 // kernel folds the splits itself (the last block to arrive of each query block does) and
 // applies the ratio test when keep != nullptr; otherwise the splits go to `part` for the merge kernel.
 int mfma_max_split_rows(int W);    // train rows one block may scan (width of its row index)
-void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
+void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
                          const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
                          const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
                          int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2,

@@ -610,8 +610,8 @@ constexpr int kRowsPerSplit = 384;   // train rows per block the plan aims at wh
 struct MatchPlan {
   int W, Q, qblocks, splits, threads;
   bool use_lds;
-  bool mfma;   // matrix-core kernel (hamming_mfma.hip); G = groups of 32 queries per wave
-  int G;
+  bool mfma;   // matrix-core kernel (hamming_mfma.hip); G = groups of 32 queries per wave,
+  int G, NW;   // NW = waves per block
   size_t off_qp, off_tp, off_part, off_cnt, total;
   bool fold_in_kernel;   // matrix-core kernel folds its splits itself (arrival counters at off_cnt)
 };
@@ -661,7 +661,12 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   p.Q = 1;
   p.mfma = default_mfma();
   p.G = 0;
-  if (g_force_variant >= 8) {
+  p.NW = 4;
+  if (g_force_variant >= 16) {          // 18: eight waves per block, two query groups per wave
+    p.mfma = true;
+    p.G = g_force_variant - 16;
+    p.NW = 8;
+  } else if (g_force_variant >= 8) {
     p.mfma = true;
     p.G = g_force_variant - 8;
   } else if (g_force_variant >= 0) {
@@ -683,16 +688,25 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
       if (idle2 - idle1 >= 128 && idle2 * 8 > max_nq) G = 1;
     }
     if (p.W == 32) G = 1;   // the query fragments of two groups of 32-word rows do not fit the registers
+    // One block of eight waves per CU (its waves share every staged train row and the two waves
+    // of a SIMD advance together) where one pair alone gives every CU such a block within 16
+    // splits: 8192 x 8192 x 61 B 19.0 us per call against 19.6; batches of pairs, whose blocks
+    // differ in length, run faster with two independent 4-wave blocks per CU (60 frames of
+    // 2000-8000 features: 0.90 ms against 1.11).
+    if (g_force_variant < 0 && n_pairs == 1 && G == 2 && (long long)slamhip_ceil_div(max_nq, 512) * 16 >= 256)
+      p.NW = 8;
+    if (p.NW == 8 && (G != 2 || p.W == 32)) p.NW = 4;
     p.G = G;
-    p.threads = kThreads;
-    p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128 * G);
+    p.threads = 64 * p.NW;
+    p.qblocks = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 32 * p.NW * G);
     const long long base_blocks = (long long)p.qblocks * (n_pairs > 0 ? n_pairs : 1);
     // Two blocks per CU when the queries alone do not give them, at most 16 splits and at
     // least one 128-row stage per split (measured, one n x n pair of 61-byte rows: n = 2048
     // 16 splits, 4096 16, 8192 16, 16384 8 are the fastest or within 2 % of it); and no
     // block longer than ~1024 train rows, so that the last blocks of a ragged batch do not
     // leave the chip idle for long.
-    long long s = (g_mfma_target_blocks + base_blocks - 1) / base_blocks;
+    const int target_blocks = p.NW == 8 ? g_mfma_target_blocks / 2 : g_mfma_target_blocks;   // one block per CU
+    long long s = (target_blocks + base_blocks - 1) / base_blocks;
     if (s > 16) s = 16;
     const int by_rows = slamhip_ceil_div(max_nt > 0 ? max_nt : 1, 128);
     if (s > by_rows) s = by_rows;
@@ -832,7 +846,7 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   launch_top2<WW, 1, true, TT, true>(grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off, d_t_cnt, d_out_off, \
                                      nqs, nts, n_out_total, part, d_idx2, d_dist2)
   if (p.mfma) {
-    slamhip_internal::launch_hamming_mfma(p.W, p.G, best_only, grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off,
+    slamhip_internal::launch_hamming_mfma(p.W, p.G, p.NW, best_only, grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off,
                                           d_t_cnt, d_out_off, nqs, nts, n_out_total, part, d_idx2, d_dist2,
                                           p.fold_in_kernel ? arrivals : nullptr, ratio, d_keep);
   } else if (best_only && p.use_lds && p.Q == 1 && p.W <= 16) {

@@ -48,16 +48,18 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 
 constexpr int kKeyShift = 21;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
-constexpr int kThreads = 256;
 
-template <int W> struct Geo {
+// NW = waves per block: 4 (two blocks share a CU) or 8 (one block per CU: its waves share every
+// staged train row, and the two waves of a SIMD advance together, stage by stage)
+template <int W, int NW> struct Geo {
+  static constexpr int NT = 64 * NW;                  // threads per block
   static constexpr int KS = W / 2;                    // matrix instructions per 32 x 32 tile
   static constexpr int CPR = W;                       // 16-byte chunks per expanded row
   static constexpr int R = SLAMHIP_MFMA_STAGE_ROWS * (W == 8 ? 2 : 1) / (W == 32 ? 2 : 1);   // train rows per stage
   static constexpr int SH = (W == 32) ? 12 : 13;      // key = (D - d) << SH | (MASK - row)
   static constexpr int MASK = (1 << SH) - 1;
-  static constexpr int UNITS = R * W / 4 / kThreads;  // 16-byte packed units per thread and stage
-  static_assert(R * W / 4 % kThreads == 0, "stage units divide over the block");
+  static constexpr int UNITS = R * W / 4 / NT;        // 16-byte packed units per thread and stage
+  static_assert(R * W / 4 % NT == 0 && R <= NT, "stage units divide over the block");
 };
 
 // Running top-2 of float keys (larger is better), invariant b1 >= b2 among valid keys.
@@ -121,15 +123,16 @@ template <int W> __device__ __forceinline__ int row_swizzle(int row) {
   return W == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
-template <int W, int G, bool BEST>
-__global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
+template <int W, int G, bool BEST, int NW>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
     const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
     const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
     uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2,
     unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep) {
-  using GEO = Geo<W>;
+  using GEO = Geo<W, NW>;
+  constexpr int kThreads = GEO::NT;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
   constexpr int D = 32 * W;
   constexpr int kStageSlots = R * CPR;                 // 16-byte slots per stage buffer
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     nt = t_cnt ? t_cnt[pair] : t_off[pair + 1] - t0;
   }
   const int o0 = out_off ? out_off[pair] : q0;
-  const int qblk = blockIdx.x * (4 * 32 * G);
+  const int qblk = blockIdx.x * (NW * 32 * G);
   if (qblk >= nq) return;  // block-uniform
 
   const int n_splits = gridDim.y;
@@ -422,7 +425,7 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
     __syncthreads();
     if (last_flag[0]) {
       if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      for (int q = tid; q < 128 * G; q += kThreads) {
+      for (int q = tid; q < NW * 32 * G; q += kThreads) {
         if (qblk + q >= nq) continue;
         const size_t row = (size_t)(o0 + qblk + q);
         uint32_t m1 = kNoKey, m2 = kNoKey;                // smallest, second smallest key
@@ -474,12 +477,12 @@ __global__ __launch_bounds__(kThreads, 2) void hamming_mfma_kernel(
 #endif
 }
 
-template <int W, int G, bool BEST>
+template <int W, int G, bool BEST, int NW>
 void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, const int32_t *q_off,
             const int32_t *q_cnt, const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off,
             int nq, int nt, int nq_total, uint2 *part, int32_t *idx2, int32_t *dist2, unsigned *arrivals,
             double ratio, uint8_t *keep) {
-  hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST>), grid, dim3(kThreads), 0, st, qp, tp, q_off, q_cnt,
+  hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW>), grid, dim3(64 * NW), 0, st, qp, tp, q_off, q_cnt,
                      t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep);
 }
 
@@ -489,22 +492,22 @@ namespace slamhip_internal {
 
 int mfma_max_split_rows(int W) { return W == 32 ? (1 << 12) : (1 << 13); }
 
-void launch_hamming_mfma(int W, int G, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
+void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
                          const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
                          const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
                          int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2,
                          unsigned *arrivals, double ratio, uint8_t *keep) {
-#define SLAMHIP_MFMA_CASE(WW, GG)                                                                    \
-  if (W == WW && G == GG) {                                                                          \
-    if (best) launch<WW, GG, true>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,    \
+#define SLAMHIP_MFMA_CASE(WW, GG, NN)                                                                \
+  if (W == WW && G == GG && NW == NN) {                                                              \
+    if (best) launch<WW, GG, true, NN>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt, \
+                                       nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep); \
+    else launch<WW, GG, false, NN>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,    \
                                    nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep);     \
-    else launch<WW, GG, false>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,        \
-                               nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep);         \
     return;                                                                                          \
   }
-  SLAMHIP_MFMA_CASE(8, 1) SLAMHIP_MFMA_CASE(8, 2)
-  SLAMHIP_MFMA_CASE(16, 1) SLAMHIP_MFMA_CASE(16, 2)
-  SLAMHIP_MFMA_CASE(32, 1)
+  SLAMHIP_MFMA_CASE(8, 1, 4) SLAMHIP_MFMA_CASE(8, 2, 4) SLAMHIP_MFMA_CASE(8, 2, 8)
+  SLAMHIP_MFMA_CASE(16, 1, 4) SLAMHIP_MFMA_CASE(16, 2, 4) SLAMHIP_MFMA_CASE(16, 2, 8)
+  SLAMHIP_MFMA_CASE(32, 1, 4)
 #undef SLAMHIP_MFMA_CASE
 }
 

@@ -61,7 +61,7 @@ def test_golden_cases(golden):
         np.testing.assert_array_equal(d, g[f"{name}_dist2"], err_msg=name)
 
 
-@pytest.mark.parametrize("variant", [0, 1, 4, 5, 8, 9, 10])
+@pytest.mark.parametrize("variant", [0, 1, 4, 5, 8, 9, 10, 18])
 @pytest.mark.parametrize("splits", [0, 1, 3, 64])
 def test_every_kernel_variant_with_ties(variant, splits):
     from slam_amd import _lib

@@ -24,7 +24,7 @@ out = (torch.empty((n, 2), dtype=torch.int32, device=q.device),
        torch.empty((n, 2), dtype=torch.int32, device=q.device),
        torch.empty(n, dtype=torch.uint8, device=q.device))
 tune = _lib.lib.slamhip_tune
-configs = [(1, 0)] + [(v, s) for v in (9, 10) for s in (0, 8, 16, 32)]
+configs = [(1, 0)] + [(v, s) for v in (9, 10, 18) for s in (0, 8, 16, 32)]
 ref = None
 best = {}
 for rnd in range(3):
