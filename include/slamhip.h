@@ -65,7 +65,11 @@ const char *slamhip_strerror(int code);
  * per block it does not exceed when blocks abound (0 = default), knob 8 = where the
  * matrix-core matcher folds its train splits (2, the default: inside the launch for small
  * calls, a merge launch for large ones; 1: always inside; 0: always a merge launch; set it
- * before sizing a workspace; same results).  Process-global; not
+ * before sizing a workspace; same results), knob 9 = the matrix-core matcher reads the
+ * caller's rows as they are (1, the default) or rows packed by a launch in front (0), knob 10 =
+ * launches of the top-2 kernel per call while the duration probe below is on (1..64, default 1:
+ * identical launches back to back between the probe's two events, which spreads the events' own
+ * cost; slamhip_profile_end then reports the time of all of them).  Process-global; not
  * for use while other threads are inside the library. */
 int slamhip_tune(int knob, int value);
 

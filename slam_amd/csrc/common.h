@@ -68,12 +68,19 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
 // arrivals != nullptr (grid.x * grid.z counters, zero at launch) with more than one split: the
 // kernel folds the splits itself (the last block to arrive of each query block does) and
 // applies the ratio test when keep != nullptr; otherwise the splits go to `part` for the merge kernel.
+// Descriptor rows as the caller stores them, for the matrix-core kernel's direct read (no packing
+// launch): qp / tp then point at the first row of each array; *_end = one past the last byte.
+struct RawRows {
+  int row_stride, desc_bytes;
+  const uint8_t *q_end, *t_end;
+};
 int mfma_max_split_rows(int W);    // train rows one block may scan (width of its row index)
 void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,
                          const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
                          const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
                          int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2,
-                         unsigned *arrivals = nullptr, double ratio = 0.0, uint8_t *keep = nullptr);
+                         unsigned *arrivals = nullptr, double ratio = 0.0, uint8_t *keep = nullptr,
+                         const RawRows *raw = nullptr);
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,

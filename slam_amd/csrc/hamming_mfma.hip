@@ -118,19 +118,42 @@ __device__ __forceinline__ v4i expand_dword(uint32_t x, uint32_t m8, uint32_t m2
   return o;
 }
 
+// 16 bytes of a descriptor row stored as it came (any alignment): the first `valid` of them
+// (<= 0 .. >= 16) belong to the row, the others read as zero.  `end` = one past the last byte
+// of the array that may be touched (the array is at least 16 bytes long): a load that would
+// reach past it is moved back to end at it, and the bytes shifted down.
+__device__ __forceinline__ uint4 load_raw16(const uint8_t *p, const uint8_t *end, int valid) {
+  const uint8_t *pc = (p + 16 <= end) ? p : end - 16;
+  unsigned __int128 x;
+  __builtin_memcpy(&x, pc, 16);
+  const int back = (int)(p - pc);               // != 0 only in the last rows of the array
+  x >>= 8 * (back < 15 ? back : 15);            // (a chunk wholly behind the row is masked out below)
+  // bytes of the row per dword: valid - 4 j of dword j
+  auto m = [&](int j) {
+    const int nb = valid - 4 * j;
+    return nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : (1u << (8 * nb)) - 1u);
+  };
+  return make_uint4((uint32_t)x & m(0), (uint32_t)(x >> 32) & m(1), (uint32_t)(x >> 64) & m(2),
+                    (uint32_t)(x >> 96) & m(3));
+}
+
 // swizzle term of a row (XORed into the 16-byte chunk index)
 template <int W> __device__ __forceinline__ int row_swizzle(int row) {
   return W == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
-template <int W, int G, bool BEST, int NW>
+// RAW: qp / tp are the caller's descriptor rows as they are (desc_bytes long, row_stride apart,
+// any alignment; q_end / t_end one past the last byte of each array) instead of rows packed to W
+// dwords: no packing launch in front.
+template <int W, int G, bool BEST, int NW, bool RAW>
 __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
     const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
     const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
     uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2,
-    unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep) {
+    unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep, int row_stride, int desc_bytes,
+    const uint8_t *__restrict__ q_end, const uint8_t *__restrict__ t_end) {
   using GEO = Geo<W, NW>;
   constexpr int kThreads = GEO::NT;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
@@ -183,9 +206,17 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     qrow[g] = qblk + (wave * G + g) * 32 + r;
-    const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W + h * KS);
+    if (RAW) {
+      const uint8_t *src = reinterpret_cast<const uint8_t *>(qp) + (size_t)(q0 + min(qrow[g], nq - 1)) * row_stride +
+                           4 * h * KS;
 #pragma unroll
-    for (int k = 0; k < KS / 4; ++k) qraw[g][k] = src[k];
+      for (int k = 0; k < KS / 4; ++k)
+        qraw[g][k] = load_raw16(src + 16 * k, q_end, desc_bytes - 4 * h * KS - 16 * k);
+    } else {
+      const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W + h * KS);
+#pragma unroll
+      for (int k = 0; k < KS / 4; ++k) qraw[g][k] = src[k];
+    }
   }
   const int scale_t = 127 + SH - 1, scale_q = 127;   // E8M0: 2^(SH-1) and 1
 
@@ -227,13 +258,16 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
       for (int j = 0; j < 4; ++j) u_dst[k][j] = (row * CPR + ((4 * c4 + j) ^ f)) * 16;
     }
     const uint32_t *tbase = tp + (size_t)t0 * W + 4 * ((tid % (W / 4)));
+    const uint8_t *traw = reinterpret_cast<const uint8_t *>(tp) + (size_t)t0 * row_stride + 16 * (tid % (W / 4));
+    const int tvalid = desc_bytes - 16 * (tid % (W / 4));     // bytes of the row in this thread's chunks
     char *const lbase = reinterpret_cast<char *>(lds);
     uint32_t ux[PIECES];
     auto load_stage = [&](int stage_begin) {
 #pragma unroll
       for (int k = 0; k < UNITS; ++k) {
         const int grow = min(stage_begin + u_row[k], r_end - 1);   // rows past the end: the last row again
-        const uint4 v = *reinterpret_cast<const uint4 *>(tbase + (size_t)grow * W);
+        const uint4 v = RAW ? load_raw16(traw + (size_t)grow * row_stride, t_end, tvalid)
+                            : *reinterpret_cast<const uint4 *>(tbase + (size_t)grow * W);
         ux[4 * k + 0] = v.x; ux[4 * k + 1] = v.y; ux[4 * k + 2] = v.z; ux[4 * k + 3] = v.w;
       }
     };
@@ -481,9 +515,15 @@ template <int W, int G, bool BEST, int NW>
 void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, const int32_t *q_off,
             const int32_t *q_cnt, const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off,
             int nq, int nt, int nq_total, uint2 *part, int32_t *idx2, int32_t *dist2, unsigned *arrivals,
-            double ratio, uint8_t *keep) {
-  hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW>), grid, dim3(64 * NW), 0, st, qp, tp, q_off, q_cnt,
-                     t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep);
+            double ratio, uint8_t *keep, const slamhip_internal::RawRows *raw) {
+  if (raw != nullptr)
+    hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, true>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,
+                       q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep,
+                       raw->row_stride, raw->desc_bytes, raw->q_end, raw->t_end);
+  else
+    hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, false>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,
+                       q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep, 0,
+                       0, nullptr, nullptr);
 }
 
 }  // namespace
@@ -496,13 +536,14 @@ void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t
                          const uint32_t *tp, const int32_t *q_off, const int32_t *q_cnt,
                          const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off, int nq,
                          int nt, int nq_total, void *part, int32_t *idx2, int32_t *dist2,
-                         unsigned *arrivals, double ratio, uint8_t *keep) {
+                         unsigned *arrivals, double ratio, uint8_t *keep, const RawRows *raw) {
 #define SLAMHIP_MFMA_CASE(WW, GG, NN)                                                                \
   if (W == WW && G == GG && NW == NN) {                                                              \
     if (best) launch<WW, GG, true, NN>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt, \
-                                       nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep); \
+                                       nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep,  \
+                                       raw);                                                         \
     else launch<WW, GG, false, NN>(grid, st, qp, tp, q_off, q_cnt, t_off, t_cnt, out_off, nq, nt,    \
-                                   nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep);     \
+                                   nq_total, (uint2 *)part, idx2, dist2, arrivals, ratio, keep, raw); \
     return;                                                                                          \
   }
   SLAMHIP_MFMA_CASE(8, 1, 4) SLAMHIP_MFMA_CASE(8, 2, 4) SLAMHIP_MFMA_CASE(8, 2, 8)

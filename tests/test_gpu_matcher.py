@@ -20,6 +20,7 @@ def _reset_tuning(request):
     _lib.lib.slamhip_tune(1, 0)
     _lib.lib.slamhip_tune(8, 2)
     _lib.lib.slamhip_tune(5, 0)
+    _lib.lib.slamhip_tune(9, 1)
 
 
 def _run(q, t):
@@ -69,16 +70,19 @@ def test_every_kernel_variant_with_ties(variant, splits):
     _lib.lib.slamhip_tune(1, splits)
     rng = np.random.default_rng(variant * 10 + splits)
     for nq, nt, d in [(1, 1, 61), (63, 65, 61), (257, 129, 32), (600, 700, 61), (300, 40, 33),
-                      (130, 513, 128), (70, 90, 1), (64, 256, 64)]:
+                      (130, 513, 128), (70, 90, 1), (64, 256, 64), (5, 3, 17), (40, 33, 49), (2, 1, 15)]:
         q = rng.integers(0, 256, (nq, d), dtype=np.uint8)
         t = rng.integers(0, 256, (nt, d), dtype=np.uint8)
         if nq % 2 == 0:  # few distinct byte values -> a lot of equal distances
             q &= 1
             t &= 1
-        i, dd = _run(q, t)
         ei, ed = so.hamming_knn2(q, t)
-        np.testing.assert_array_equal(i, ei, err_msg=f"{nq}x{nt}x{d}")
-        np.testing.assert_array_equal(dd, ed, err_msg=f"{nq}x{nt}x{d}")
+        # knob 9: the matrix-core kernel reads the rows as they are (1) or packed by a launch in front (0)
+        for raw in ((1, 0) if variant >= 8 else (1,)):
+            _lib.lib.slamhip_tune(9, raw)
+            i, dd = _run(q, t)
+            np.testing.assert_array_equal(i, ei, err_msg=f"{nq}x{nt}x{d} raw={raw}")
+            np.testing.assert_array_equal(dd, ed, err_msg=f"{nq}x{nt}x{d} raw={raw}")
 
 
 @pytest.mark.parametrize("threads", [128, 256])
@@ -338,7 +342,7 @@ def test_facade_errors_like_reference():
 
 @pytest.mark.parametrize("desc_bytes,stride,offset", [(61, 61, 0), (61, 61, 1), (61, 67, 3), (32, 32, 2),
                                                       (64, 64, 1), (64, 70, 0), (1, 1, 0), (5, 9, 3),
-                                                      (128, 128, 3), (100, 101, 2)])
+                                                      (128, 128, 3), (100, 101, 2), (33, 40, 1), (17, 17, 0), (49, 49, 5), (16, 16, 1), (15, 15, 0)])
 def test_rows_at_any_alignment_and_stride(desc_bytes, stride, offset):
     """Through the C ABI with rows at an arbitrary byte offset and stride (the row
     packer fetches aligned dwords and funnel-shifts): results equal the oracle.

@@ -24,10 +24,10 @@ int main(int argc, char **argv) {
     HIPCHECK(hipMemcpy(dq, hq.data(), hq.size(), hipMemcpyHostToDevice));
     HIPCHECK(hipMemcpy(dt, ht.data(), ht.size(), hipMemcpyHostToDevice));
     HIPCHECK(hipMalloc(&di, (size_t)n * 8)); HIPCHECK(hipMalloc(&dd, (size_t)n * 8)); HIPCHECK(hipMalloc(&keep, n));
-    for (int variant : {10, 18}) {
+    for (int variant : {-1}) {
       for (int fold : {2}) {
         
-        for (int splits : {0, 8, 16, 32}) {
+        for (int splits : {0}) {
           slamhip_tune(0, variant); slamhip_tune(1, splits); slamhip_tune(8, fold);
           const size_t wsb = slamhip_hamming_knn2_workspace_bytes(n, n, 1, n, n, D);
           HIPCHECK(hipMalloc(&ws, wsb));
