@@ -67,8 +67,8 @@ OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
 # 8 / 16 / 32 dwords.  Peak: MI355X block-scaled FP4 MFMA, dense (no sparsity).
 MFMA_PEAK_FLOPS = 10.0e15
 # HBM-side bytes per matrix-core top-2 launch, same recipe (profiles/r2/pmc_matcher8k_mfma.txt):
-# FETCH_SIZE 2374 KB x2 + WRITE_SIZE 1024 KB.
-PMC_TRAFFIC_BYTES_MFMA = (2374 * 2 + 1024) * 1024
+# FETCH_SIZE 2276 KB x2 + WRITE_SIZE 1024 KB.
+PMC_TRAFFIC_BYTES_MFMA = (2276 * 2 + 1024) * 1024
 
 
 def flop_per_compare(desc_bytes, issued=False):
