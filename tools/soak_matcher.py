@@ -17,6 +17,8 @@ for case in range(cases):
     _lib.lib.slamhip_tune(3, int(rng.choice([0, 128, 256])))
     _lib.lib.slamhip_tune(0, int(rng.choice([-1, -1, 1, 9, 10])))
     _lib.lib.slamhip_tune(8, int(rng.choice([0, 1, 2])))
+    _lib.lib.slamhip_tune(9, int(rng.choice([1, 1, 0])))
+    _lib.lib.slamhip_tune(0, int(rng.choice([-1, -1, 1, 9, 10, 18])))
     n_pairs = int(rng.choice([1, 2, 5]))
     big = rng.random() < 0.2
     nqs = [int(rng.integers(0, 3000 if big else 400)) for _ in range(n_pairs)]
