@@ -13,19 +13,24 @@
 // train row: the order of a sequential scan with strict `<` insertion
 // (cv2.BFMatcher / batchDistance, the tie rule behind
 // frontend/vision/descriptor_matcher.py:33 of the reference).  What is left for
-// the vector ALU per (query, train row) is the running top-2 update: v_med3 + v_max.
+// the vector ALU per (query, train row) is the running top-2 update (v_med3 / v_max3, 20
+// instructions per 16 keys).
 //
 // Work decomposition
-//   block  = 256 threads = 4 waves; wave = G groups of 32 queries whose expanded
-//            rows stay in registers (B operand) for the whole scan
+//   block  = NW waves (4, or 8 for one large pair); wave = G groups of 32 queries whose
+//            expanded rows stay in registers (B operand) for the whole scan
 //   grid   = (query blocks, train splits, pairs), as the popcount kernel
-//   stage  = R train rows: loaded as packed dwords (coalesced 16-byte loads), expanded
-//            to FP4 on the fly (one dword -> four dwords: bit plane p of the dword,
-//            (x << (3 - p)) & 0x88888888 | 0x22222222), written to LDS in a
-//            16-byte-slot XOR swizzle that makes the A-fragment ds_read_b128 of 32
-//            rows conflict-free; double buffered, one barrier per stage.  A table of
-//            the stage's C_in values sits beside it (rows past the end hold a large
-//            negative number, so they can never win).
+//   stage  = R train rows: loaded 16 bytes per thread, either from rows packed to W dwords or
+//            from the caller's rows as they are (RAW: unaligned loads, bytes behind the row
+//            masked off), expanded to FP4 on the fly (one dword -> four dwords: bit plane p of
+//            the dword, (x << (3 - p)) & 0x88888888 | 0x22222222), written to LDS in a
+//            16-byte-slot XOR swizzle that makes the A-fragment ds_read_b128 of 32 rows
+//            conflict-free; two buffers, one barrier per stage.  A table of the stage's C_in
+//            values sits beside it (rows past the end hold a large negative number, so they
+//            can never win).
+//   loop   = software pipeline: every k-step issues its matrix instructions, re-fills the A
+//            fragment it has just used with the next tile's, folds a slice of the previous
+//            tile's keys into the running top-2 and expands one piece of the next stage.
 //   tile   = 32 train rows x 32 queries: KS = W / 2 matrix instructions per group.
 // Accumulator layout (32 x 32): lane l holds query column l & 31 and train rows
 // (i & 3) + 8 (i >> 2) + 4 (l >> 5), i = 0..15; lanes l and l ^ 32 meet at the end.
