@@ -58,8 +58,10 @@ const char *slamhip_strerror(int code);
  * screening in the consensus counting kernels (1 = on, the default; 0 = fp64 only;
  * the counts are identical either way), knob 3 = matcher block size (0 auto, 256 or
  * 128 queries per block), knob 4 = pair RANSAC launch scheme (0 auto: calls with at
- * most 64 pairs solve and count every hypothesis in one pass; 1 always rounds of 256
- * hypotheses; identical results; set it before sizing a workspace), knob 5 = sort
+ * most 64 pairs solve and count every hypothesis in one pass, longer front-end calls run
+ * three rounds of 256 hypotheses and the rest of the cap as one merged launch; 1 always
+ * rounds of 256; 2 rounds with the merged tail whatever the pair count; identical results;
+ * set it before sizing a workspace), knob 5 = sort
  * algorithm (0 auto, 1 rank counting, 2 bitonic network where the segments fit it;
  * same order), knob 6 / 7 = matrix-core matcher: blocks a launch aims at / train rows
  * per block it does not exceed when blocks abound (0 = default), knob 8 = where the

@@ -38,13 +38,17 @@ namespace slamhip_internal {
 // fp64 (same counts); 0: fp64 only.  Set through slamhip_tune(2, value).
 extern int g_ransac_screen;
 // Pair RANSAC launch scheme: 0 = chosen from the number of pairs (single pass for few
-// pairs), 1 = always rounds of 256 hypotheses.  Set through slamhip_tune(4, value).
+// pairs; three rounds and a merged tail for the front-end's long calls), 1 = always rounds
+// of 256 hypotheses, 2 = rounds with the merged tail.  Set through slamhip_tune(4, value).
 extern int g_ransac_mode;
 
 // splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                             int desc_bytes, long long n_out = -1, bool prepacked = false,
                             int splits = 0);
+// Whether the matcher reads such a call's rows as the caller stores them (any stride, no packing
+// launch, no packed copy in its workspace) when they are not handed over prepacked.
+bool knn2_reads_raw(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt, int desc_bytes);
 // Number of train splits the matcher chooses for a launch of n_pairs pairs of at most
 // max_nq x max_nt rows.  A caller that runs several launches through one workspace
 // passes the value of its largest launch to every one of them.

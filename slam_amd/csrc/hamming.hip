@@ -644,7 +644,7 @@ bool default_mfma() {
 }
 int g_force_splits = 0;
 int g_mfma_target_blocks = 512;    // matrix-core kernel: blocks a launch aims at (knob 6)
-int g_mfma_rows_per_split = 1024;  // and train rows per block it does not exceed when blocks abound (knob 7)
+int g_mfma_rows_per_split = 4096;  // and train rows per block it does not exceed when blocks abound (knob 7)
 int g_prof_repeat = 1;     // knob 10: launches of the top-2 kernel per probed call (see run_knn2)
 int g_raw_rows = 1;        // knob 9: matrix-core kernel reads unpacked rows itself (0 = packing launch first)
 int g_fold_in_kernel = 2;  // knob 8: 0 = always the separate merge launch, 1 = never, 2 = by size
@@ -706,8 +706,10 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
     // Two blocks per CU when the queries alone do not give them, at most 16 splits and at
     // least one 128-row stage per split (measured, one n x n pair of 61-byte rows: n = 2048
     // 16 splits, 4096 16, 8192 16, 16384 8 are the fastest or within 2 % of it); and no
-    // block longer than ~1024 train rows, so that the last blocks of a ragged batch do not
-    // leave the chip idle for long.
+    // block longer than 4096 train rows (measured on batches, whose query blocks alone fill the
+    // chip: 500 frames of 1500 features 0.82 ms per pass with at most 1024 rows per block,
+    // 0.79 with 2048 or more: no split, no merge launch; 60 frames of 2000-8000 features
+    // 0.91 / 0.87 / 0.86 / 0.89 ms with 1024 / 2048 / 4096 / 8192).
     const int target_blocks = p.NW == 8 ? g_mfma_target_blocks / 2 : g_mfma_target_blocks;   // one block per CU
     long long s = (target_blocks + base_blocks - 1) / base_blocks;
     if (s > 16) s = 16;
@@ -751,11 +753,14 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   if (g_force_splits > 0) s = g_force_splits > kMaxSplits ? kMaxSplits : g_force_splits;
   p.splits = (int)s;
   }
+  p.raw = p.mfma && !prepacked && g_raw_rows != 0 && (long long)nq_total * desc_bytes >= 16 &&
+          (nt_total == 0 || (long long)nt_total * desc_bytes >= 16);   // see below
+  const bool packs = !prepacked && !p.raw;
   size_t o = 0;
   p.off_qp = o;
-  if (!prepacked) o = slamhip_align_up(o + (size_t)nq_total * p.W * 4, 256);
+  if (packs) o = slamhip_align_up(o + (size_t)nq_total * p.W * 4, 256);
   p.off_tp = o;
-  if (!prepacked) o = slamhip_align_up(o + (size_t)nt_total * p.W * 4, 256);
+  if (packs) o = slamhip_align_up(o + (size_t)nt_total * p.W * 4, 256);
   p.off_part = o;
   if (p.splits > 1) o = slamhip_align_up(o + (size_t)p.splits * (size_t)n_out * sizeof(uint2), 256);
   // The matrix-core kernel folds its splits inside the launch when the call has a row
@@ -771,8 +776,6 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   // clear the arrival counters, and a fill launch in its place costs what the merge launch
   // costs (2048 x 2048: 7.9 us per call with the merge launch, 10.0 folded behind a fill), so
   // the fold in the kernel is left to calls that pack (knob 9 = 0) or ask for it (knob 8 = 1).
-  p.raw = p.mfma && !prepacked && g_raw_rows != 0 && (long long)nq_total * desc_bytes >= 16 &&
-          (nt_total == 0 || (long long)nt_total * desc_bytes >= 16);
   const bool fold_wanted = g_fold_in_kernel == 1 || (g_fold_in_kernel == 2 && !p.raw && compares <= (8ll << 20));
   p.fold_in_kernel = p.mfma && p.splits > 1 && !prepacked && fold_wanted;
   p.off_cnt = o;
@@ -967,7 +970,7 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 4) slamhip_internal::g_ransac_mode = value;
   else if (knob == 5) g_force_sort = value;
   else if (knob == 6) g_mfma_target_blocks = value > 0 ? value : 512;
-  else if (knob == 7) g_mfma_rows_per_split = value > 0 ? value : 1024;
+  else if (knob == 7) g_mfma_rows_per_split = value > 0 ? value : 4096;
   else if (knob == 9) g_raw_rows = value ? 1 : 0;
   else if (knob == 10) g_prof_repeat = value >= 1 && value <= 64 ? value : 1;
   else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
@@ -1162,6 +1165,10 @@ namespace slamhip_internal {
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                             int desc_bytes, long long n_out, bool prepacked, int splits) {
   return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, n_out, prepacked, splits).total;
+}
+
+bool knn2_reads_raw(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt, int desc_bytes) {
+  return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, 0, false).raw;
 }
 
 int knn2_plan_splits(int n_pairs, int max_nq, int max_nt, int desc_bytes) {

@@ -99,6 +99,7 @@ __global__ __launch_bounds__(kBlock) void stereo_points_kernel(
     const int32_t *__restrict__ off_left, const int32_t *__restrict__ st_count,
     const int32_t *__restrict__ st_left, const float *__restrict__ st_pix_left,
     const float *__restrict__ st_pix_right, const uint32_t *__restrict__ packed_left, int W,
+    const uint8_t *__restrict__ raw_left, int raw_stride, int desc_bytes, size_t raw_bytes,
     CamPair cam, float *__restrict__ st_xyz, uint32_t *__restrict__ st_desc) {
   const int f = blockIdx.y;
   const int base = off_left[f], m = st_count[f];
@@ -118,9 +119,28 @@ __global__ __launch_bounds__(kBlock) void stereo_points_kernel(
   // descriptor rows of this block's inliers, in inlier order (W is a power of two)
   const int rows = min(kBlock, m - i0);
   const int lw = W == 8 ? 3 : (W == 16 ? 4 : 5);
-  for (int e = threadIdx.x; e < rows * W; e += kBlock) {
-    const int r = i0 + (e >> lw), w = e & (W - 1);
-    st_desc[(size_t)(base + r) * W + w] = packed_left[(size_t)(base + st_left[base + r]) * W + w];
+  if (raw_left == nullptr) {
+    for (int e = threadIdx.x; e < rows * W; e += kBlock) {
+      const int r = i0 + (e >> lw), w = e & (W - 1);
+      st_desc[(size_t)(base + r) * W + w] = packed_left[(size_t)(base + st_left[base + r]) * W + w];
+    }
+  } else {
+    // the caller's rows (any stride and alignment; raw_bytes >= 4): dword loads that never
+    // leave the array -- one that would is moved back to its end and shifted -- and zeros
+    // behind the descriptor's last byte, which is what a packed row holds
+    for (int e = threadIdx.x; e < rows * W; e += kBlock) {
+      const int r = i0 + (e >> lw), w = e & (W - 1);
+      const int nb = desc_bytes - 4 * w;            // descriptor bytes from this word on
+      uint32_t v = 0u;
+      if (nb > 0) {
+        const size_t at = (size_t)(base + st_left[base + r]) * raw_stride + 4 * w;
+        const size_t from = at + 4 <= raw_bytes ? at : raw_bytes - 4;
+        __builtin_memcpy(&v, raw_left + from, 4);
+        v >>= 8 * (int)(at - from);
+        if (nb < 4) v &= (1u << (8 * nb)) - 1u;
+      }
+      st_desc[(size_t)(base + r) * W + w] = v;
+    }
   }
 }
 
@@ -334,15 +354,22 @@ struct RansacParams {
 };
 
 // grid (pairs, slots).  A launch covers `slots` consecutive blocks of kHypPerRound
-// hypotheses per pair: 1 in the round scheme; all of them (round 0 only, no replay
-// in between) when a call has so few pairs that launches, not arithmetic, bound it.
+// hypotheses per pair, starting at block `first_block`: 1 in the round scheme; all of them
+// (first_block 0, no replay in between) when a call has so few pairs that launches, not
+// arithmetic, bound it; the rounds left after the first few of a long run in one go (the
+// merged tail).  `replay`: first replay block first_block - 1 (one slot per pair only: the
+// replay updates the pair's state); `generate`: sample and solve (a launch with replay
+// alone brings the state up to date for a multi-slot launch that follows).
 // Pose table layout: rt[((pair * slots + slot) * 12 + element) * kHypPerRound + lane].
+// `list` (may be null): list[0] counts, and list[1..] names, the table rows this launch
+// generated hypotheses for; a launch with `generate` off clears the count instead.
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void ransac_solve_kernel(
-    int round, int slots, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
-    const float *__restrict__ cx, const float *__restrict__ cpl,
+    int first_block, int slots, int replay, int generate, const int32_t *__restrict__ obase,
+    const int32_t *__restrict__ tm_count, const float *__restrict__ cx, const float *__restrict__ cpl,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
-    int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info) {
+    int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info,
+    int32_t *__restrict__ list) {
   __shared__ int sh[3];  // stopped, winner lane of the replayed round, iterations required
   __shared__ int red[4 + kBlock / 64];
   const int p = blockIdx.x, slot = blockIdx.y;
@@ -350,7 +377,7 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
   int winner = -1;
-  if (round == 0) {
+  if (first_block == 0) {
     // every slot's block works out the same start state; slot 0 records it
     const int skip = (n >= 4 && n >= prm.min_points) ? 0 : 1;
     if (threadIdx.x == 0) {
@@ -362,9 +389,9 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
       sh[1] = -1;
       sh[2] = prm.n_iter_max;
     }
-  } else {                 // round scheme only (slots == 1)
-    if (!s[7])             // same value in every thread: written by an earlier launch
-      winner = replay_round(s, counts + row * kHypPerRound, round - 1, n, prm.n_iter_max,
+  } else {
+    if (replay && !s[7])   // slots == 1; s[7]: same value in every thread, written by an earlier launch
+      winner = replay_round(s, counts + row * kHypPerRound, first_block - 1, n, prm.n_iter_max,
                             log(1.0 - prm.p_success), red);
     if (threadIdx.x == 0) {
       sh[0] = s[7];
@@ -374,18 +401,21 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
   }
   __syncthreads();
   if (threadIdx.x < 12 && slot == 0) {
-    if (round == 0)
+    if (first_block == 0)
       pose_ransac[12 * (size_t)p + threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;  // [I|0]
     else if (sh[1] >= 0)
       pose_ransac[12 * (size_t)p + threadIdx.x] = rt[(row * 12 + threadIdx.x) * kHypPerRound + sh[1]];
   }
-  if (sh[0]) return;
+  if (list != nullptr && !generate && p == 0 && threadIdx.x == 0) list[0] = 0;   // the next launch appends
+  if (sh[0] || !generate) return;
   __syncthreads();  // the winner has been read before its slot is overwritten
 
   // The required iteration count only ever shrinks, so a hypothesis at or beyond the
   // current requirement can never be consumed by the replay: it is not generated.
-  const int it = (round * slots + slot) * kHypPerRound + (int)threadIdx.x;
+  const int it = (first_block + slot) * kHypPerRound + (int)threadIdx.x;
   const bool active = it < prm.n_iter_max && it < sh[2];
+  if (list != nullptr && threadIdx.x == 0 && active)      // lane 0 holds the block's first hypothesis
+    list[1 + atomicAdd(&list[0], 1)] = (int32_t)row;
   bool valid = false;
   if (active) {
     const float *X = cx + 3 * (size_t)obase[p];
@@ -435,22 +465,21 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
 // thousands.
 // MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair.
 constexpr int kWideRounds = 3;
+// One wavefront's share: hypotheses [64 * hyp_group, +64) of table row `row` (a block of
+// pair p's hypotheses) against the pair's correspondences [span0, span0 + span_len).
 template <int MODE>
-__device__ __forceinline__ void ransac_count_body(
+__device__ __forceinline__ void ransac_count_item(
+    double *lds, int p, size_t row, int hyp_group, int span0, int span_len,
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span, int slots) {
+    const int32_t *__restrict__ info) {
   constexpr bool screened = MODE != 0;
-  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
-  const int p = blockIdx.z;
-  const size_t row = (size_t)p * slots + blockIdx.y / (kHypPerRound / 64);
   if (info[8 * (size_t)p + 7]) return;
   const int n = tm_count[p];
-  const int span0 = blockIdx.x * (chunks_per_span * kPtsPerChunk);
   if (span0 >= n) return;
-  const int span1 = min(n, span0 + chunks_per_span * kPtsPerChunk);
-  const int hyp = (int)(blockIdx.y % (kHypPerRound / 64)) * 64 + (int)threadIdx.x;
+  const int span1 = min(n, span0 + span_len);
+  const int hyp = hyp_group * 64 + (int)threadIdx.x;
   int32_t *slot = counts + row * kHypPerRound + hyp;
   // a valid hypothesis' slot starts at 0 and only grows; invalid ones hold -1 / -2
   const bool valid = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
@@ -501,6 +530,44 @@ __device__ __forceinline__ void ransac_count_body(
   if (valid && c) atomicAdd(slot, c);
 }
 
+template <int MODE>
+__device__ __forceinline__ void ransac_count_body(
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
+    const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
+    const int32_t *__restrict__ info, int chunks_per_span, int slots) {
+  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
+  const int p = blockIdx.z;
+  ransac_count_item<MODE>(lds, p, (size_t)p * slots + blockIdx.y / (kHypPerRound / 64),
+                          (int)(blockIdx.y % (kHypPerRound / 64)), blockIdx.x * (chunks_per_span * kPtsPerChunk),
+                          chunks_per_span * kPtsPerChunk, obase, tm_count, cx, cpl, cpr, cam, thresh, rt,
+                          counts, info);
+}
+
+// The merged tail's counting launch: a fixed grid of wavefronts strides over the work the
+// solve launch listed -- `list[0]` rows (pair * slots + slot) from list[1] on, each
+// kHypPerRound / 64 hypothesis groups x `chunks` chunks of correspondences -- so that pairs
+// which stopped long ago cost neither blocks nor time, and the few that go on get the whole
+// chip.  The counts are integer sums: the order of the list does not show in them.
+template <int MODE>
+__device__ __forceinline__ void ransac_count_list_body(
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
+    const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
+    const int32_t *__restrict__ info, int chunks, int slots, const int32_t *__restrict__ list) {
+  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
+  constexpr int kGroups = kHypPerRound / 64;
+  const long long n_items = (long long)list[0] * kGroups * chunks;
+  for (long long w = blockIdx.x; w < n_items; w += gridDim.x) {
+    const int chunk = (int)(w % chunks);
+    const int hyp_group = (int)((w / chunks) % kGroups);
+    const int row = list[1 + w / ((long long)chunks * kGroups)];
+    ransac_count_item<MODE>(lds, row / slots, (size_t)row, hyp_group, chunk * kPtsPerChunk, kPtsPerChunk,
+                            obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info);
+    __syncthreads();   // the staged chunk has been read by every lane before the next item's overwrites it
+  }
+}
+
 #define SLAMHIP_COUNT_ARGS                                                                         \
   const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,                         \
       const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,  \
@@ -520,6 +587,16 @@ __global__ __launch_bounds__(64) void ransac_count_screened_kernel(SLAMHIP_COUNT
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void ransac_count_rectified_kernel(SLAMHIP_COUNT_ARGS) {
   ransac_count_body<2>(SLAMHIP_COUNT_PASS);
+}
+__global__ __launch_bounds__(64) void ransac_count_list_fp64_kernel(SLAMHIP_COUNT_ARGS, const int32_t *__restrict__ list) {
+  ransac_count_list_body<0>(SLAMHIP_COUNT_PASS, list);
+}
+__global__ __launch_bounds__(64) void ransac_count_list_screened_kernel(SLAMHIP_COUNT_ARGS, const int32_t *__restrict__ list) {
+  ransac_count_list_body<1>(SLAMHIP_COUNT_PASS, list);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ransac_count_list_rectified_kernel(SLAMHIP_COUNT_ARGS, const int32_t *__restrict__ list) {
+  ransac_count_list_body<2>(SLAMHIP_COUNT_PASS, list);
 }
 
 // Replays the hypothesis blocks not replayed yet (the last round's one, or all
@@ -587,26 +664,43 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
 // kHypPerRound at most) and replays them all in the finishing launch -- 3 launches
 // instead of 2 per round.  Same samples, same replay order, same outcome.
 constexpr int kMaxSlots = 16;
+constexpr int kTailGrid = 4096;         // wavefronts of the merged tail's counting launch: 4 per SIMD
 constexpr int kSinglePassPairs = 64;    // measured break-even against the adaptive rounds at ~40 % inliers
 
 int single_pass_slots(int n_pairs, int n_iter_max) {
   const int slots = slamhip_ceil_div(n_iter_max > 0 ? n_iter_max : 1, kHypPerRound);
-  const int mode = slamhip_internal::g_ransac_mode;      // 0 auto, 1 rounds always
-  if (slots < 2 || slots > kMaxSlots || mode == 1) return 1;
+  const int mode = slamhip_internal::g_ransac_mode;      // 0 auto, 1 rounds always, 2 rounds with the merged tail
+  if (slots < 2 || slots > kMaxSlots || mode == 1 || mode == 2) return 1;
   if (n_pairs > kSinglePassPairs) return 1;
   return slots;
 }
 
+// The rounds after the first kWideRounds reach few pairs (those with a small consensus set):
+// each would be two launches that find nearly nothing to do.  With `merge_tail` they run as ONE
+// multi-slot launch pair without replays in between (as the single pass does), behind a launch
+// that only replays the last wide round; the finishing launch replays the tail's blocks in
+// order, so the outcome is that of the rounds one by one.  Its pose / count tables have a row
+// per (pair, tail block).
+int tail_slots(int n_iter_max, bool merge_tail) {
+  const int rounds = slamhip_ceil_div(n_iter_max > 0 ? n_iter_max : 1, kHypPerRound);
+  return (merge_tail && rounds >= kWideRounds + 2) ? rounds - kWideRounds : 0;
+}
+
+size_t ransac_table_bytes(size_t rows, bool listed = false) {
+  return slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256) +
+         slamhip_align_up(rows * kHypPerRound * sizeof(int32_t), 256) +
+         (listed ? slamhip_align_up((rows + 1) * sizeof(int32_t), 256) : 0);
+}
+
 // Sized for any call with at most n_pairs pairs (a caller may run its last, shorter
 // batch through the same workspace, and a short batch may take the single pass).
-size_t ransac_workspace_bytes(int n_pairs, int n_iter_max) {
+size_t ransac_workspace_bytes(int n_pairs, int n_iter_max, bool merge_tail = false) {
   const size_t g = (size_t)(n_pairs < kPairGroup ? (n_pairs > 0 ? n_pairs : 1) : kPairGroup);
   size_t rows = g;
   const int most = n_pairs < kSinglePassPairs ? n_pairs : kSinglePassPairs;   // largest single-pass call
   const size_t single = (size_t)most * single_pass_slots(most, n_iter_max);
   if (single > rows) rows = single;
-  return slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256) +
-         slamhip_align_up(rows * kHypPerRound * sizeof(int32_t), 256);
+  return ransac_table_bytes(rows) + ransac_table_bytes(g * (size_t)tail_slots(n_iter_max, merge_tail), true);
 }
 
 // RANSAC for pairs [0, n_pairs) described by obase / tm_count; `prm.pair0` is
@@ -614,36 +708,64 @@ size_t ransac_workspace_bytes(int n_pairs, int n_iter_max) {
 int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *cx, const float *cpl,
                     const float *cpr, const int32_t *samples, RansacParams prm, int n_pairs,
                     int max_points, double *pose_ransac, uint8_t *tm_mask, int32_t *info, void *ws,
-                    hipStream_t st) {
+                    hipStream_t st, bool merge_tail = false) {
   if (n_pairs <= 0) return SLAMHIP_OK;
   const int group = n_pairs < kPairGroup ? n_pairs : kPairGroup;
   const int slots = single_pass_slots(n_pairs, prm.n_iter_max);
-  const size_t rows = (size_t)group * slots;
+  // table sizes as ransac_workspace_bytes lays them out for the caller's largest call
+  const size_t g_max = (size_t)group;
+  size_t rows = g_max;
+  if ((size_t)group * slots > rows) rows = (size_t)group * slots;
   double *rt = (double *)ws;
   int32_t *counts =
       (int32_t *)((uintptr_t)ws + slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256));
-  const int rounds = slots > 1 ? 1 : slamhip_ceil_div(prm.n_iter_max, kHypPerRound);
+  const int tail = (slots > 1 || slamhip_internal::g_ransac_mode == 1) ? 0 : tail_slots(prm.n_iter_max, merge_tail);
+  double *rt_tail = (double *)((uintptr_t)ws + ransac_table_bytes(rows));
+  int32_t *counts_tail = (int32_t *)((uintptr_t)rt_tail +
+                                     slamhip_align_up(g_max * tail * 12 * kHypPerRound * sizeof(double), 256));
+  int32_t *list = (int32_t *)((uintptr_t)counts_tail +
+                              slamhip_align_up(g_max * tail * kHypPerRound * sizeof(int32_t), 256));
+  const int rounds = slots > 1 ? 1 : (tail ? kWideRounds : slamhip_ceil_div(prm.n_iter_max, kHypPerRound));
   const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
   const long long pair0 = prm.pair0;
   const int mode = screening_mode(slamhip_internal::g_ransac_screen, prm.cam.K, prm.cam.MR, prm.thresh);
   for (int g0 = 0; g0 < n_pairs; g0 += group) {
     const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
     prm.pair0 = pair0 + g0;
+    auto count = mode == 2 ? ransac_count_rectified_kernel
+                 : mode == 1 ? ransac_count_screened_kernel : ransac_count_fp64_kernel;
     for (int r = 0; r < rounds; ++r) {
-      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, slots), dim3(kBlock), 0, st, r, slots, obase + g0,
-                         tm_count + g0, cx, cpl, samples, prm, rt, counts,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0);
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, slots), dim3(kBlock), 0, st, r, slots, r > 0 ? 1 : 0, 1,
+                         obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
       const dim3 cgrid(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np);
-      auto count = mode == 2 ? ransac_count_rectified_kernel
-                   : mode == 1 ? ransac_count_screened_kernel : ransac_count_fp64_kernel;
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
                          prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots);
     }
-    hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds - 1, slots,
-                       obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt, counts,
-                       pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
+    if (tail) {
+      // replay of the last wide round (state and winner pose up to date), then every block left
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, 1), dim3(kBlock), 0, st, kWideRounds, 1, 1, 0,
+                         obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list);
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, tail), dim3(kBlock), 0, st, kWideRounds, tail, 0, 1,
+                         obase + g0, tm_count + g0, cx, cpl, samples, prm, rt_tail, counts_tail,
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list);
+      auto count_list = mode == 2 ? ransac_count_list_rectified_kernel
+                        : mode == 1 ? ransac_count_list_screened_kernel : ransac_count_list_fp64_kernel;
+      const long long most = (long long)np * tail * (kHypPerRound / 64) * chunks;
+      hipLaunchKernelGGL(count_list, dim3((unsigned)(most < kTailGrid ? most : kTailGrid)), dim3(64), 0, st,
+                         obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt_tail, counts_tail,
+                         info + 8 * (size_t)g0, chunks, tail, list);
+      hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, kWideRounds, tail,
+                         obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt_tail, counts_tail,
+                         pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
+    } else {
+      hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds - 1, slots,
+                         obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt, counts,
+                         pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
+    }
     SLAMHIP_CHECK_LAUNCH();
   }
   return SLAMHIP_OK;
@@ -654,7 +776,10 @@ struct Layout {
   size_t idx2, dist2, order, packL, packR, knn, tidx2, tdist2, order2, cx, cpl, cpr, tcount, ransac, total;
   size_t ridx2, rdist2, bid;   // cross-check only: the swapped matcher's result, the bids
   size_t knn_bytes;
+  bool raw;                    // the stereo matcher reads the caller's descriptor rows: no packed copy
 };
+
+constexpr int kInPlaceRows = 4096;   // features per image up to which the stereo matcher reads unpacked rows
 
 Layout make_layout(const slamhip_frontend_args *a) {
   Layout L;
@@ -663,18 +788,28 @@ Layout make_layout(const slamhip_frontend_args *a) {
   size_t o = 0;
   auto take = [&](size_t bytes) { const size_t at = o; o = slamhip_align_up(o + bytes, 256); return at; };
   L.idx2 = take(NL * 8); L.dist2 = take(NL * 8); L.order = take(NL * 4);
-  L.packL = take(NL * L.W * 4); L.packR = take(NR * L.W * 4);
   const int F = a->n_frames > 0 ? a->n_frames : 1;
+  // In place where the matcher's kernel can and a frame is a few query blocks: every one of them
+  // reads the frame's train rows again, and the unaligned, masked read costs more than the aligned
+  // one (measured per pass, in place against packed first: 500 frames of 1500 features 0.755 /
+  // 0.779 ms, 250 of 3000 1.031 / 1.040, 100 of 2000-8000 1.67 / 1.65).
+  L.raw = a->max_left <= kInPlaceRows && a->max_right <= kInPlaceRows &&
+          slamhip_internal::knn2_reads_raw(a->n_left_total, a->n_right_total, F, a->max_left,
+                                           a->max_right, a->desc_bytes) &&
+          (!a->stereo_cross_check ||
+           slamhip_internal::knn2_reads_raw(a->n_right_total, a->n_left_total, F, a->max_right,
+                                            a->max_left, a->desc_bytes));
+  L.packL = take(L.raw ? 0 : NL * L.W * 4); L.packR = take(L.raw ? 0 : NR * L.W * 4);
   const size_t k1 = slamhip_internal::knn2_workspace_bytes(a->n_left_total, a->n_right_total, F,
-                                                           a->max_left, a->max_right, a->desc_bytes);
+                                                           a->max_left, a->max_right, a->desc_bytes, -1, !L.raw);
   const size_t k2 = slamhip_internal::knn2_workspace_bytes(a->n_left_total, a->n_left_total,
                                                            F > 1 ? F - 1 : 1, a->max_left, a->max_left,
-                                                           a->desc_bytes);
+                                                           a->desc_bytes, -1, true);
   L.knn_bytes = k1 > k2 ? k1 : k2;
   L.ridx2 = L.rdist2 = L.bid = 0;
   if (a->stereo_cross_check || a->temporal_cross_check) {
     const size_t k3 = slamhip_internal::knn2_workspace_bytes(a->n_right_total, a->n_left_total, F,
-                                                             a->max_right, a->max_left, a->desc_bytes);
+                                                             a->max_right, a->max_left, a->desc_bytes, -1, !L.raw);
     if (k3 > L.knn_bytes) L.knn_bytes = k3;
     const size_t rows = NL > NR ? NL : NR;
     L.ridx2 = take(rows * 8); L.rdist2 = take(rows * 8); L.bid = take(NL * 4);
@@ -683,7 +818,7 @@ Layout make_layout(const slamhip_frontend_args *a) {
   L.tidx2 = take(NL * 8); L.tdist2 = take(NL * 8); L.order2 = take(NL * 4);
   L.cx = take(NL * 12); L.cpl = take(NL * 8); L.cpr = take(NL * 8);
   L.tcount = take((size_t)F * 4);
-  L.ransac = take(ransac_workspace_bytes(F - 1, a->n_iter_max));
+  L.ransac = take(ransac_workspace_bytes(F - 1, a->n_iter_max, true));
   L.total = o + 256;
   return L;
 }
@@ -753,14 +888,22 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   }
 
   // ---- stereo stage
-  rc = slamhip_internal::pack_rows(a->d_des_left, a->n_left_total, packL, a->d_des_right,
-                                   a->n_right_total, packR, a->desc_bytes, a->desc_stride, st);
-  if (rc) return rc;
+  // The stereo matcher reads the caller's rows as they are where its kernel can; otherwise
+  // from a packed copy (W dwords a row, zero padded) made here.
+  const uint8_t *rowsL = a->d_des_left, *rowsR = a->d_des_right;
+  int rows_stride = a->desc_stride;
+  if (!L.raw) {
+    rc = slamhip_internal::pack_rows(a->d_des_left, a->n_left_total, packL, a->d_des_right,
+                                     a->n_right_total, packR, a->desc_bytes, a->desc_stride, st);
+    if (rc) return rc;
+    rowsL = (const uint8_t *)packL; rowsR = (const uint8_t *)packR;
+    rows_stride = W * 4;
+  }
   int32_t *ridx2 = (int32_t *)(base + L.ridx2), *rdist2 = (int32_t *)(base + L.rdist2);
   uint32_t *bid = (uint32_t *)(base + L.bid);
   if (!a->stereo_cross_check) {
-    rc = slamhip_internal::knn2((const uint8_t *)packL, a->n_left_total, (const uint8_t *)packR,
-                                a->n_right_total, a->desc_bytes, W * 4, true, a->d_off_left, nullptr,
+    rc = slamhip_internal::knn2(rowsL, a->n_left_total, rowsR,
+                                a->n_right_total, a->desc_bytes, rows_stride, !L.raw, a->d_off_left, nullptr,
                                 a->d_off_right, nullptr, F, a->max_left, a->max_right, idx2, dist2,
                                 knn_ws, L.knn_bytes, st, nullptr, -1, true);
     if (rc) return rc;
@@ -768,8 +911,8 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
     if (hipMemsetAsync(bid, 0xFF, sizeof(uint32_t) * (size_t)a->n_left_total, st) != hipSuccess)
       return SLAMHIP_ELAUNCH;
     if (a->n_right_total > 0 && a->max_right > 0) {
-      rc = slamhip_internal::knn2((const uint8_t *)packR, a->n_right_total, (const uint8_t *)packL,
-                                  a->n_left_total, a->desc_bytes, W * 4, true, a->d_off_right, nullptr,
+      rc = slamhip_internal::knn2(rowsR, a->n_right_total, rowsL,
+                                  a->n_left_total, a->desc_bytes, rows_stride, !L.raw, a->d_off_right, nullptr,
                                   a->d_off_left, nullptr, F, a->max_right, a->max_left, ridx2, rdist2,
                                   knn_ws, L.knn_bytes, st, nullptr, -1, true);
       if (rc) return rc;
@@ -791,7 +934,10 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                      a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
   hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F), dim3(kBlock),
                      0, st, a->d_off_left, a->d_st_count, a->d_st_left, a->d_st_pix_left,
-                     a->d_st_pix_right, packL, W, cam, a->d_st_xyz, a->d_st_desc);
+                     a->d_st_pix_right, packL, W, L.raw ? a->d_des_left : nullptr, a->desc_stride,
+                     a->desc_bytes,
+                     (size_t)(a->n_left_total - 1) * a->desc_stride + a->desc_bytes, cam, a->d_st_xyz,
+                     a->d_st_desc);
   SLAMHIP_CHECK_LAUNCH();
   if (F < 2) return SLAMHIP_OK;
 
@@ -841,7 +987,8 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   prm.pair0 = 0;
   prm.seq0 = a->first_pair;
   rc = run_pair_ransac(a->d_off_left, tcount, cx, cpl, cpr, a->d_samples, prm, F - 1, a->max_left,
-                       a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st);
+                       a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st,
+                       /*merge_tail=*/true);
   if (rc) return rc;
 
   rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, a->d_off_left, tcount, F - 1, a->K,

@@ -257,13 +257,15 @@ def test_batched_cross_check_equals_frame_at_a_time(stereo_cc, frame_cc):
     assert np.abs(res.pair(0)["Rt"][:, 3] - seq.relative_pose(1)[:, 3]).max() < 0.1
 
 
-@pytest.mark.parametrize("scheme", [1, 0])       # tune knob 4: 1 = rounds, 0 = auto (single pass here)
+# tune knob 4: 1 = rounds, 0 = auto (single pass here), 2 = three rounds, then the rest of the cap in one launch
+@pytest.mark.parametrize("scheme", [1, 0, 2])
 @pytest.mark.parametrize("seed,n_iter,clutter,thresh", [(31, 1100, 0.72, 4.0), (5, 257, 0.5, 2.0),
                                                         (77, 2500, 0.8, 1.5)])
 def test_ransac_rounds_equal_stand_alone_kernels(seed, n_iter, clutter, thresh, scheme):
-    """The batched RANSAC in both launch schemes -- rounds of 256 hypotheses (late
+    """The batched RANSAC in its launch schemes -- rounds of 256 hypotheses (late
     rounds on the narrow grid, hypotheses beyond the current requirement not
-    generated) and the single pass a call with few pairs takes -- against the
+    generated), the single pass a call with few pairs takes, and the rounds with
+    everything after the third merged into one launch (long calls) -- against the
     same samples pushed through the stand-alone kernels one pair at a time:
     P3P -> consensus counts -> sequential replay.  Same device arithmetic, so
     winner, count, iteration trace, pose and mask must agree exactly, for pairs
@@ -558,3 +560,48 @@ def test_device_record_equals_the_host_record_byte_for_byte(nbytes):
         a, c = whole.frame(f), res.frame(f)
         for k in c:
             np.testing.assert_array_equal(a[k], c[k], err_msg=k)
+
+
+@pytest.mark.parametrize("nbytes", [61, 32, 16])
+@pytest.mark.parametrize("cross", [False, True])
+def test_frontend_reads_descriptor_rows_in_place(nbytes, cross):
+    """The stereo matcher and the inlier-descriptor gather read the caller's rows where
+    they lie (61-byte rows: nothing aligned, a tail to mask in every row, the last row
+    ending at the array's last byte) -- every output, the packed inlier descriptors
+    included, equals the run that packs the rows first (tune knob 9 = 0)."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    F = 5
+    seq = StereoSequence(cam, n_frames=F, n_features=(300, 900), seed=nbytes + cross, clutter=0.5, nbytes=nbytes)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(F))]
+    fe = TrackingFrontend(cam, n_iter_max=300, seed=3, stereo_cross_check=cross, frame_cross_check=cross)
+    inp = fe.upload(frames)
+
+    def snapshot():
+        res = fe.run(inp)
+        rows = [res.frame(f) for f in range(F)] + [res.pair(p) for p in range(F - 1)]
+        host = res.to_host()
+        return [{k: np.array(v, copy=True) for k, v in r.items() if isinstance(v, np.ndarray)} for r in rows], host
+
+    try:
+        _lib.lib.slamhip_tune(9, 1)
+        a, ha = snapshot()
+        _lib.lib.slamhip_tune(9, 0)
+        fe._ws = None
+        b, hb = snapshot()
+    finally:
+        _lib.lib.slamhip_tune(9, 1)
+    assert sum(len(r["xyz"]) for r in a[:F]) > 200
+    for x, y in zip(a, b):
+        assert x.keys() == y.keys()
+        for k in x:
+            np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+    # the packed inlier descriptor rows the temporal matcher reads, zero padding included
+    W = 8 if nbytes <= 32 else 16
+    da, db = ha["st_desc"].reshape(-1, W), hb["st_desc"].reshape(-1, W)
+    for f in range(F):
+        o, m = int(inp.off_left[f]), int(ha["st_count"][f])
+        np.testing.assert_array_equal(da[o:o + m], db[o:o + m])
+        assert not da[o:o + m].view(np.uint8)[:, nbytes:].any()

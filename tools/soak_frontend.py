@@ -1,7 +1,9 @@
 """One-off soak of the batched front-end for run-to-run determinism and agreement of its
 launch schemes: random sequences (2..40 frames, 60..2500 features per image, both
-cross-check flags, random iteration caps), each run twice and once more with the RANSAC
-round scheme forced; every valid output row must be identical bit for bit.
+cross-check flags, random iteration caps), each run twice and once more with each of the
+other RANSAC launch schemes forced (rounds; rounds with the merged tail) and once with the
+descriptor rows packed in front of the stereo matcher; every valid output row must be
+identical bit for bit.
 python tools/soak_frontend.py [cases]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -53,11 +55,18 @@ for case in range(cases):
     b = snapshot(fe.run(inp), F)
     _lib.lib.slamhip_tune(4, 1)
     c = snapshot(fe.run(inp), F)
+    _lib.lib.slamhip_tune(4, 2)
+    d = snapshot(fe.run(inp), F)
     _lib.lib.slamhip_tune(4, 0)
-    r1, r2 = same(a, b), same(a, c)
-    if r1 is not True or r2 is not True:
+    _lib.lib.slamhip_tune(9, 0)          # descriptor rows packed first instead of read in place
+    fe._ws = None
+    e = snapshot(fe.run(inp), F)
+    _lib.lib.slamhip_tune(9, 1)
+    fe._ws = None
+    r1, r2, r3, r4 = same(a, b), same(a, c), same(a, d), same(a, e)
+    if r1 is not True or r2 is not True or r3 is not True or r4 is not True:
         bad += 1
-        print(f"MISMATCH case {case}: F={F} nfeat={nfeat} rerun={r1} rounds={r2}", flush=True)
+        print(f"MISMATCH case {case}: F={F} nfeat={nfeat} rerun={r1} rounds={r2} tail={r3} packed={r4}", flush=True)
     if case % 5 == 0:
         print(f"case {case} ok so far (F={F}, features {nfeat}), mismatches {bad}", flush=True)
 print(f"done: {cases} cases, {bad} mismatches")
