@@ -23,12 +23,19 @@ __device__ __forceinline__ bool jacobi_pair(double (&a)[4][4], double (&v)[4][4]
     beta = fma(a[i][Qc], a[i][Qc], beta);
     gamma = fma(a[i][P], a[i][Qc], gamma);
   }
-  // Columns already orthogonal to working precision.
-  if (fabs(gamma) <= 2.220446049250313e-16 * sqrt(alpha * beta) || gamma == 0.0) return false;
-  const double zeta = (beta - alpha) / (2.0 * gamma);
-  const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(fma(zeta, zeta, 1.0)));
-  const double c = 1.0 / sqrt(fma(t, t, 1.0));
-  const double s = c * t;
+  // Columns already orthogonal to working precision: |gamma| <= eps sqrt(alpha beta), squared.
+  if (gamma * gamma <= 4.930380657631324e-32 * (alpha * beta)) return false;
+  // The rotation with tan(theta) = t = sign(zeta) / (|zeta| + sqrt(1 + zeta^2)), zeta = (beta - alpha) /
+  // (2 gamma), written without a division: with d = beta - alpha, g = 2 gamma, h = hypot(d, g) and
+  // D = |d| + h it is t = sign(d) g / D, so cos = D / sqrt(D^2 + g^2), sin = sign(d) g / sqrt(D^2 + g^2).
+  // (Two reciprocal square roots; the quotient-and-root form costs three divisions and two roots,
+  // which was most of the kernel's time.)
+  const double d = beta - alpha, g = gamma + gamma;
+  const double hh = fma(d, d, g * g);
+  const double D = fabs(d) + hh * rsqrt(hh);
+  const double r = rsqrt(fma(D, D, g * g));
+  const double c = D * r;
+  const double s = (d < 0.0 ? -g : g) * r;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const double ap = a[i][P], aq = a[i][Qc];
@@ -77,7 +84,7 @@ __device__ __forceinline__ void smallest_right_singular_vector(double (&a)[4][4]
     x[i] = k == 0 ? v[i][0] : (k == 1 ? v[i][1] : (k == 2 ? v[i][2] : v[i][3]));
   // V is a product of rotations, so the column is unit length up to rounding;
   // renormalise so the fp32 rounding below sees a unit vector like an SVD's.
-  const double inv = 1.0 / sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
+  const double inv = rsqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3]);
 #pragma unroll
   for (int i = 0; i < 4; ++i) x[i] *= inv;
 }

@@ -363,13 +363,16 @@ struct RansacParams {
 // Pose table layout: rt[((pair * slots + slot) * 12 + element) * kHypPerRound + lane].
 // `list` (may be null): list[0] counts, and list[1..] names, the table rows this launch
 // generated hypotheses for; a launch with `generate` off clears the count instead.
+// `hyp32` (may be null): per valid hypothesis the fp32 image of its projection matrices and
+// its error-bound constants (Hyp32), hyp32[(row * kHyp32Floats + field) * kHypPerRound + lane].
+constexpr int kHyp32Floats = 32;   // 29 used: PL[12], PR[12], A3xy, Atxy, A3w, Atw, cR
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void ransac_solve_kernel(
     int first_block, int slots, int replay, int generate, const int32_t *__restrict__ obase,
     const int32_t *__restrict__ tm_count, const float *__restrict__ cx, const float *__restrict__ cpl,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
     int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info,
-    int32_t *__restrict__ list) {
+    int32_t *__restrict__ list, float *__restrict__ hyp32) {
   __shared__ int sh[3];  // stopped, winner lane of the replayed round, iterations required
   __shared__ int red[4 + kBlock / 64];
   const int p = blockIdx.x, slot = blockIdx.y;
@@ -451,8 +454,22 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
       if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
     }
     valid = p3p_lane(Xs, f, nrm4, Rt);
-    if (valid)
+    if (valid) {
       for (int i = 0; i < 12; ++i) rt[(row * 12 + i) * kHypPerRound + threadIdx.x] = Rt[i];
+      if (hyp32 != nullptr) {
+        // what the counting launch's fp32 screen needs of this hypothesis, worked out once here
+        // instead of once per (64 hypotheses, 128 points) block there
+        double PL[12], PR[12];
+        make_projections(Rt, prm.cam, PL, PR);
+        Hyp32 h;
+        make_hyp32(PL, PR, h);
+        float *o = hyp32 + row * kHyp32Floats * kHypPerRound + threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) { o[i * kHypPerRound] = h.PL[i]; o[(12 + i) * kHypPerRound] = h.PR[i]; }
+        o[24 * kHypPerRound] = h.A3xy; o[25 * kHypPerRound] = h.Atxy; o[26 * kHypPerRound] = h.A3w;
+        o[27 * kHypPerRound] = h.Atw;  o[28 * kHypPerRound] = h.cR;
+      }
+    }
   }
   counts[row * kHypPerRound + threadIdx.x] = active ? (valid ? 0 : -1) : -2;
 }
@@ -473,7 +490,7 @@ __device__ __forceinline__ void ransac_count_item(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info) {
+    const int32_t *__restrict__ info, const float *__restrict__ hyp32) {
   constexpr bool screened = MODE != 0;
   if (info[8 * (size_t)p + 7]) return;
   const int n = tm_count[p];
@@ -484,16 +501,35 @@ __device__ __forceinline__ void ransac_count_item(
   // a valid hypothesis' slot starts at 0 and only grows; invalid ones hold -1 / -2
   const bool valid = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
   if (!__any(valid)) return;
-  double PL[12], PR[12];
-  {
+  // the hypothesis' fp64 projections: the fp64 path's; the screened loop keeps their fp32 image
+  // only (as the solve launch left it, or worked out here) and comes back for these for the
+  // one point in thousands it cannot decide -- 48 registers less through the loop
+  auto projections = [&](double (&PL_)[12], double (&PR_)[12]) {
     double Rt[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i)
       Rt[i] = valid ? rt[(row * 12 + i) * kHypPerRound + hyp] : 0.0;
-    make_projections(Rt, cam, PL, PR);
-  }
+    make_projections(Rt, cam, PL_, PR_);
+  };
+  double PL[12], PR[12];
   Hyp32 h32;
-  if (screened) make_hyp32(PL, PR, h32);
+  if (!screened) {
+    projections(PL, PR);
+  } else if (hyp32 != nullptr) {
+    const float *o = hyp32 + row * kHyp32Floats * kHypPerRound + hyp;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+      h32.PL[i] = valid ? o[i * kHypPerRound] : 0.0f;
+      h32.PR[i] = (MODE == 1 && valid) ? o[(12 + i) * kHypPerRound] : 0.0f;
+    }
+    h32.A3xy = valid ? o[24 * kHypPerRound] : 0.0f; h32.Atxy = valid ? o[25 * kHypPerRound] : 0.0f;
+    h32.A3w = valid ? o[26 * kHypPerRound] : 0.0f;  h32.Atw = valid ? o[27 * kHypPerRound] : 0.0f;
+    h32.cR = valid ? o[28 * kHypPerRound] : 0.0f;
+  } else {
+    double PL_[12], PR_[12];
+    projections(PL_, PR_);
+    make_hyp32(PL_, PR_, h32);
+  }
   const double thr2 = threshold_squared(thresh);
   float *ldsf = reinterpret_cast<float *>(lds);
   int c = 0;
@@ -522,7 +558,11 @@ __device__ __forceinline__ void ransac_count_item(
     __syncthreads();
     if (valid) {
       if (screened)
-        c += count_chunk_inliers_screened<MODE == 2>(ldsf, cnt, PL, PR, h32, sc, thresh, thr2);
+        c += count_chunk_inliers_screened<MODE == 2>(ldsf, cnt, h32, sc, thr2, [&](const float *f) {
+          double PL_[12], PR_[12];
+          projections(PL_, PR_);
+          return inlier_exact_staged<MODE == 2>(f, PL_, PR_, thresh, thr2);
+        });
       else
         c += count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
     }
@@ -535,13 +575,13 @@ __device__ __forceinline__ void ransac_count_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span, int slots) {
+    const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   const int p = blockIdx.z;
   ransac_count_item<MODE>(lds, p, (size_t)p * slots + blockIdx.y / (kHypPerRound / 64),
                           (int)(blockIdx.y % (kHypPerRound / 64)), blockIdx.x * (chunks_per_span * kPtsPerChunk),
                           chunks_per_span * kPtsPerChunk, obase, tm_count, cx, cpl, cpr, cam, thresh, rt,
-                          counts, info);
+                          counts, info, hyp32);
 }
 
 // The merged tail's counting launch: a fixed grid of wavefronts strides over the work the
@@ -554,7 +594,8 @@ __device__ __forceinline__ void ransac_count_list_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks, int slots, const int32_t *__restrict__ list) {
+    const int32_t *__restrict__ info, int chunks, int slots, const float *__restrict__ hyp32,
+    const int32_t *__restrict__ list) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   constexpr int kGroups = kHypPerRound / 64;
   const long long n_items = (long long)list[0] * kGroups * chunks;
@@ -563,7 +604,7 @@ __device__ __forceinline__ void ransac_count_list_body(
     const int hyp_group = (int)((w / chunks) % kGroups);
     const int row = list[1 + w / ((long long)chunks * kGroups)];
     ransac_count_item<MODE>(lds, row / slots, (size_t)row, hyp_group, chunk * kPtsPerChunk, kPtsPerChunk,
-                            obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info);
+                            obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, hyp32);
     __syncthreads();   // the staged chunk has been read by every lane before the next item's overwrites it
   }
 }
@@ -572,8 +613,8 @@ __device__ __forceinline__ void ransac_count_list_body(
   const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,                         \
       const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,  \
       RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,   \
-      const int32_t *__restrict__ info, int chunks_per_span, int slots
-#define SLAMHIP_COUNT_PASS obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, chunks_per_span, slots
+      const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32
+#define SLAMHIP_COUNT_PASS obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, chunks_per_span, slots, hyp32
 
 __global__ __launch_bounds__(64) void ransac_count_fp64_kernel(SLAMHIP_COUNT_ARGS) {
   ransac_count_body<0>(SLAMHIP_COUNT_PASS);
@@ -686,10 +727,26 @@ int tail_slots(int n_iter_max, bool merge_tail) {
   return (merge_tail && rounds >= kWideRounds + 2) ? rounds - kWideRounds : 0;
 }
 
-size_t ransac_table_bytes(size_t rows, bool listed = false) {
-  return slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256) +
-         slamhip_align_up(rows * kHypPerRound * sizeof(int32_t), 256) +
-         (listed ? slamhip_align_up((rows + 1) * sizeof(int32_t), 256) : 0);
+// Where the tables of a call lie in its workspace: pose / count / fp32-image tables of
+// `rows` rows (a row = one block of kHypPerRound hypotheses of one pair), then the merged
+// tail's pose / count tables of `tail_rows` rows and its work list.  Every offset grows with
+// the row counts, so a call lays its own, smaller tables out inside a workspace sized for the
+// caller's largest call.
+struct RansacTables {
+  size_t rt, counts, hyp32, rt_tail, counts_tail, list, total;
+};
+RansacTables ransac_tables(size_t rows, size_t tail_rows) {
+  RansacTables t;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o = slamhip_align_up(o + bytes, 256); return at; };
+  t.rt = take(rows * 12 * kHypPerRound * sizeof(double));
+  t.counts = take(rows * kHypPerRound * sizeof(int32_t));
+  t.hyp32 = take(rows * kHyp32Floats * kHypPerRound * sizeof(float));
+  t.rt_tail = take(tail_rows * 12 * kHypPerRound * sizeof(double));
+  t.counts_tail = take(tail_rows * kHypPerRound * sizeof(int32_t));
+  t.list = take((tail_rows + 1) * sizeof(int32_t));
+  t.total = o;
+  return t;
 }
 
 // Sized for any call with at most n_pairs pairs (a caller may run its last, shorter
@@ -700,7 +757,7 @@ size_t ransac_workspace_bytes(int n_pairs, int n_iter_max, bool merge_tail = fal
   const int most = n_pairs < kSinglePassPairs ? n_pairs : kSinglePassPairs;   // largest single-pass call
   const size_t single = (size_t)most * single_pass_slots(most, n_iter_max);
   if (single > rows) rows = single;
-  return ransac_table_bytes(rows) + ransac_table_bytes(g * (size_t)tail_slots(n_iter_max, merge_tail), true);
+  return ransac_tables(rows, g * (size_t)tail_slots(n_iter_max, merge_tail)).total;
 }
 
 // RANSAC for pairs [0, n_pairs) described by obase / tm_count; `prm.pair0` is
@@ -712,23 +769,20 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
   if (n_pairs <= 0) return SLAMHIP_OK;
   const int group = n_pairs < kPairGroup ? n_pairs : kPairGroup;
   const int slots = single_pass_slots(n_pairs, prm.n_iter_max);
-  // table sizes as ransac_workspace_bytes lays them out for the caller's largest call
-  const size_t g_max = (size_t)group;
-  size_t rows = g_max;
-  if ((size_t)group * slots > rows) rows = (size_t)group * slots;
-  double *rt = (double *)ws;
-  int32_t *counts =
-      (int32_t *)((uintptr_t)ws + slamhip_align_up(rows * 12 * kHypPerRound * sizeof(double), 256));
   const int tail = (slots > 1 || slamhip_internal::g_ransac_mode == 1) ? 0 : tail_slots(prm.n_iter_max, merge_tail);
-  double *rt_tail = (double *)((uintptr_t)ws + ransac_table_bytes(rows));
-  int32_t *counts_tail = (int32_t *)((uintptr_t)rt_tail +
-                                     slamhip_align_up(g_max * tail * 12 * kHypPerRound * sizeof(double), 256));
-  int32_t *list = (int32_t *)((uintptr_t)counts_tail +
-                              slamhip_align_up(g_max * tail * kHypPerRound * sizeof(int32_t), 256));
+  const RansacTables T = ransac_tables((size_t)group * slots, (size_t)group * tail);
+  double *rt = (double *)((uintptr_t)ws + T.rt);
+  int32_t *counts = (int32_t *)((uintptr_t)ws + T.counts);
+  double *rt_tail = (double *)((uintptr_t)ws + T.rt_tail);
+  int32_t *counts_tail = (int32_t *)((uintptr_t)ws + T.counts_tail);
+  int32_t *list = (int32_t *)((uintptr_t)ws + T.list);
   const int rounds = slots > 1 ? 1 : (tail ? kWideRounds : slamhip_ceil_div(prm.n_iter_max, kHypPerRound));
   const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
   const long long pair0 = prm.pair0;
   const int mode = screening_mode(slamhip_internal::g_ransac_screen, prm.cam.K, prm.cam.MR, prm.thresh);
+  // the screened counting launches take each hypothesis' fp32 image from the solve launch (the
+  // merged tail, which few pairs reach, works it out itself and needs no table)
+  float *hyp32 = mode != 0 ? (float *)((uintptr_t)ws + T.hyp32) : nullptr;
   for (int g0 = 0; g0 < n_pairs; g0 += group) {
     const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
     prm.pair0 = pair0 + g0;
@@ -737,27 +791,28 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
     for (int r = 0; r < rounds; ++r) {
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, slots), dim3(kBlock), 0, st, r, slots, r > 0 ? 1 : 0, 1,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr);
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr, hyp32);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
       const dim3 cgrid(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np);
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
-                         prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots);
+                         prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots,
+                         (const float *)hyp32);
     }
     if (tail) {
       // replay of the last wide round (state and winner pose up to date), then every block left
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, 1), dim3(kBlock), 0, st, kWideRounds, 1, 1, 0,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list);
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr);
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, tail), dim3(kBlock), 0, st, kWideRounds, tail, 0, 1,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt_tail, counts_tail,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list);
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr);
       auto count_list = mode == 2 ? ransac_count_list_rectified_kernel
                         : mode == 1 ? ransac_count_list_screened_kernel : ransac_count_list_fp64_kernel;
       const long long most = (long long)np * tail * (kHypPerRound / 64) * chunks;
       hipLaunchKernelGGL(count_list, dim3((unsigned)(most < kTailGrid ? most : kTailGrid)), dim3(64), 0, st,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt_tail, counts_tail,
-                         info + 8 * (size_t)g0, chunks, tail, list);
+                         info + 8 * (size_t)g0, chunks, tail, (const float *)nullptr, (const int32_t *)list);
       hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, kWideRounds, tail,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt_tail, counts_tail,
                          pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);

@@ -139,13 +139,16 @@ __device__ __forceinline__ int count_chunk_inliers(const double *__restrict__ ld
 // is about 0.2 % of the threshold, far outside the 1e-10 band in which the fp64 path
 // falls back to the literal formula.
 //
-// Domain.  The bound assumes that nothing overflows, so screening is confined to
-// sum |P entries| <= 1e9, s <= 1e4, umax <= 1e5 and thr <= 1e3 (then lhs, rhs < 1e37);
-// outside, or with anything not finite, T is made NaN or infinite (Ca for a
-// hypothesis or a chunk, s^2 for a point), no comparison with it holds and the fp64
-// path decides.  Results that underflow in fp32 carry an absolute error below 2^-126
-// times the operand they are multiplied with; Cb has a floor of 1e-30 for them, and
-// strict comparisons leave diff = T = 0 undecided.
+// Domain.  The bound assumes that nothing overflows.  The matrices are screened as P times the
+// power of two that brings their largest entry into [0.5, 1) (make_hyp32; the test is
+// homogeneous in P, the scaling is exact), and screening is confined to s <= 1e4, umax <= 1e5
+// and thr <= 1e3: then |x|, |y|, |w| <= 1e4 + 1, |d| <= 1e9 + 1e4 and lhs, rhs < 1e19.  Outside,
+// or with anything not finite, T is made NaN or infinite (Ca for a hypothesis or a chunk, s^2
+// for a point), no comparison with it holds and the fp64 path decides.  An entry of the scaled
+// P below 2^-126 loses at most 2^-126 absolutely when it is rounded to fp32 (or flushed), which
+// moves x, y, w by at most 1.2e-34 (s <= 1e4), d by 1.2e-29 and lhs by 4 |d| 1.2e-29 <= 5e-20,
+// rhs by less; results that underflow later carry less still.  Cb has a floor of 1e-18 for
+// these, and strict comparisons leave diff = T = 0 undecided.
 //
 // Rectified pair: when the right camera is the left one shifted along x
 // (M_right = [I | (tx, 0, 0)]) and K is upper triangular, make_projections gives
@@ -162,7 +165,7 @@ constexpr float kEps32 = 5.9604645e-8f;
 constexpr float kAbsErr = 8.0f * kEps32 * 1.01f;
 constexpr float kRelEps = 16.0f * kEps32 * 1.01f;
 constexpr double kScreenMaxThr = 1e3;   // screening domain (see above)
-constexpr double kScreenMaxP = 1e9;
+constexpr double kScreenMaxP = 24.0;    // sum |entries| of the scaled matrices (finite <=> below it)
 constexpr float kScreenMaxS = 1e4f;
 constexpr float kScreenMaxPix = 1e5f;
 
@@ -195,13 +198,27 @@ static inline int screening_mode(int enabled, const double *K, const double *MR,
 }
 
 __device__ __forceinline__ void make_hyp32(const double (&PL)[12], const double (&PR)[12], Hyp32 &h) {
+  // The test is homogeneous in the projection matrices (x, y and w scale together, lhs and rhs
+  // with the square), so the fp32 image is taken of both matrices times one power of two that
+  // brings their largest entry into [0.5, 1): exact, and no hypothesis is outside the screen's
+  // range for its size alone.  That matters: a minimal sample with a repeated pixel (two
+  // matches of one keypoint) yields finite poses with |t| of 1e7 ... 1e31, about one hypothesis
+  // in two thousand, and each of them would otherwise send its whole wavefront through the
+  // fp64 path for every point.
+  double big = 0.0;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) big = fmax(big, fmax(fabs(PL[i]), fabs(PR[i])));   // fmax drops NaN: see `total`
+  int e = 0;
+  if (big > 0.0 && big <= 1.7976931348623157e308) (void)frexp(big, &e);
+  const double scale = ldexp(1.0, -e);
   double a3xy = 0.0, atxy = 0.0, a3w = 0.0, atw = 0.0, total = 0.0;
 #pragma unroll
   for (int i = 0; i < 12; ++i) {
-    h.PL[i] = (float)PL[i];
-    h.PR[i] = (float)PR[i];
-    const double m = fmax(fabs(PL[i]), fabs(PR[i]));
-    total += fabs(PL[i]) + fabs(PR[i]);   // NaN or infinite if any entry is
+    const double l = PL[i] * scale, r = PR[i] * scale;
+    h.PL[i] = (float)l;
+    h.PR[i] = (float)r;
+    const double m = fmax(fabs(l), fabs(r));
+    total += fabs(l) + fabs(r);   // NaN or infinite if any entry is
     if (i < 8) {
       if ((i & 3) == 3) atxy = fmax(atxy, m); else a3xy = fmax(a3xy, m);
     } else {
@@ -212,7 +229,7 @@ __device__ __forceinline__ void make_hyp32(const double (&PL)[12], const double 
   h.Atxy = (float)(atxy * 1.000001);
   h.A3w = (float)(a3w * 1.000001);
   h.Atw = (float)(atw * 1.000001);
-  h.cR = (float)(PL[3] - PR[3]);
+  h.cR = (float)((PL[3] - PR[3]) * scale);
 }
 
 // Writes the staged record of the point pair (a, b) (b = a when the chunk has an
@@ -266,83 +283,138 @@ __device__ __forceinline__ Screen32 make_screen(const Hyp32 &h, unsigned umax_bi
   Screen32 sc;
   sc.aT = 2.0f * r * thr2f * 1.000001f * inv;
   sc.ca = (g1 * (Da * Da) + g2 * (dwa * dwa)) * inv;
-  sc.cb = (g1 * (Db * Db) + g2 * (dwb * dwb)) * inv + 1e-30f;
+  sc.cb = (g1 * (Db * Db) + g2 * (dwb * dwb)) * inv + 1e-18f;
   if (!(umax <= kScreenMaxPix)) sc.ca = __builtin_nanf("");
   return sc;
 }
 
-// Inliers (both cameras) among `cnt` points staged as pairs (stage_pair).
+// The packed-fp32 screen of one staged pair of points: in* = inside both cameras for sure;
+// open* = lanes (of those active) whose point 0 / 1 is not decided -- neither inside for sure
+// nor outside one camera for sure.  The lane masks come from ballots of the bare comparisons
+// and are combined as 64-bit integers, which stays in scalar registers.
 template <bool RECT>
+__device__ __forceinline__ void screen_pair(const float *__restrict__ rec, const Hyp32 &h, f2 nthr2f,
+                                            f2 aT, f2 ca, f2 cb, bool &in0, bool &in1,
+                                            unsigned long long &open0, unsigned long long &open1) {
+  const f2 *q = reinterpret_cast<const f2 *>(rec);
+  const f2 X = q[0], Y = q[1], Z = q[2];
+  const f2 C = fma2(q[7], ca, cb);
+  const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
+  const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
+  const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
+  const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
+  const f2 w2 = w * w;
+  const f2 dL = fma2(nthr2f, w2, fma2(dx, dx, dy * dy));   // lhs - rhs, left camera
+  const f2 TL = fma2(aT, w2, C);
+  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+  if (RECT) {
+    const f2 xr = x - h.cR;
+    const f2 dxr = fma2(q[5], w, -xr), dyr = fma2(q[6], w, -y);
+    const f2 dR = fma2(nthr2f, w2, fma2(dxr, dxr, dyr * dyr));
+    // one threshold for both cameras: the larger diff decides.  fmaxf drops a NaN
+    // operand, but whatever makes one diff NaN makes T NaN or infinite as well
+    const float m0 = fmaxf(dL.x, dR.x), m1 = fmaxf(dL.y, dR.y);
+    in0 = m0 < -TL.x; in1 = m1 < -TL.y;
+    open0 = active & ~(__builtin_amdgcn_ballot_w64(in0) | __builtin_amdgcn_ballot_w64(m0 > TL.x));
+    open1 = active & ~(__builtin_amdgcn_ballot_w64(in1) | __builtin_amdgcn_ballot_w64(m1 > TL.y));
+  } else {
+    const f2 xr = fma2(splat(h.PR[0]), X, fma2(splat(h.PR[1]), Y, fma2(splat(h.PR[2]), Z, splat(h.PR[3]))));
+    const f2 yr = fma2(splat(h.PR[4]), X, fma2(splat(h.PR[5]), Y, fma2(splat(h.PR[6]), Z, splat(h.PR[7]))));
+    const f2 wr = fma2(splat(h.PR[8]), X, fma2(splat(h.PR[9]), Y, fma2(splat(h.PR[10]), Z, splat(h.PR[11]))));
+    const f2 dxr = fma2(q[5], wr, -xr), dyr = fma2(q[6], wr, -yr);
+    const f2 wr2 = wr * wr;
+    const f2 dR = fma2(nthr2f, wr2, fma2(dxr, dxr, dyr * dyr));
+    const f2 TR = fma2(aT, wr2, C);
+    in0 = dL.x < -TL.x && dR.x < -TR.x; in1 = dL.y < -TL.y && dR.y < -TR.y;
+    // decided: surely inside both cameras, or surely outside one of them
+    open0 = active & ~((__builtin_amdgcn_ballot_w64(dL.x < -TL.x) & __builtin_amdgcn_ballot_w64(dR.x < -TR.x)) |
+                       __builtin_amdgcn_ballot_w64(dL.x > TL.x) | __builtin_amdgcn_ballot_w64(dR.x > TR.x));
+    open1 = active & ~((__builtin_amdgcn_ballot_w64(dL.y < -TL.y) & __builtin_amdgcn_ballot_w64(dR.y < -TR.y)) |
+                       __builtin_amdgcn_ballot_w64(dL.y > TL.y) | __builtin_amdgcn_ballot_w64(dR.y > TR.y));
+  }
+}
+
+// fp64 decision for the staged point at f (lane k of its pair: f = record + k).
+template <bool RECT>
+__device__ __forceinline__ bool inlier_exact_staged(const float *__restrict__ f, const double (&PL)[12],
+                                                    const double (&PR)[12], double thr, double thr2) {
+  const double Xd = (double)f[0], Yd = (double)f[2], Zd = (double)f[4];
+  bool in = inlier_one_camera(PL, Xd, Yd, Zd, (double)f[6], (double)f[8], thr, thr2);
+  if (RECT) {
+    // P_right is P_left with another [3] (as numbers: [7] and [11] carry 0 * (t_x + tx)
+    // on top, which is not 0 only when t_x + tx is not finite; then P_right[3] is not
+    // finite either, the right x is infinite or NaN and the point is no inlier)
+    const double Pr[12] = {PL[0], PL[1], PL[2],  PR[3], PL[4], PL[5],
+                           PL[6], PL[7], PL[8], PL[9], PL[10], PL[11]};
+    in = in && fabs(PR[3]) <= 1.7976931348623157e308 &&
+         inlier_one_camera(Pr, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
+  } else {
+    in = in && inlier_one_camera(PR, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
+  }
+  return in;
+}
+
+// Inliers (both cameras) among `cnt` points staged as pairs (stage_pair), cnt <= 128.
+// `exact(f)`: the fp64 decision for the staged point at f (inlier_exact_staged with the
+// hypothesis' fp64 projections, which the caller may work out only when asked).
+//
+// The loop over the pairs is straight-line code -- screen, count the sure inliers, and note in
+// a scalar bit mask which pairs left any lane undecided (about one in a hundred) -- so that the
+// compiler can overlap consecutive pairs (LDS reads of the next with the arithmetic of this
+// one); a branch to the fp64 path inside it kept every iteration waiting for its own reads.
+// The noted pairs are screened again afterwards and their undecided lanes take the fp64 path.
+template <bool RECT, class Exact>
 __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restrict__ lds, int cnt,
-                                                            const double (&PL)[12],
-                                                            const double (&PR)[12], const Hyp32 &h,
-                                                            Screen32 sc, double thr, double thr2) {
+                                                            const Hyp32 &h, Screen32 sc, double thr2,
+                                                            Exact &&exact) {
   // uniform: keep it in scalar registers
   const f2 nthr2f = splat(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
       __builtin_bit_cast(int, -(float)thr2))));
   const f2 aT = splat(sc.aT), ca = splat(sc.ca), cb = splat(sc.cb);
   int c = 0;
-  const int pairs = (cnt + 1) >> 1;
-  for (int j = 0; j < pairs; ++j) {
-    const f2 *q = reinterpret_cast<const f2 *>(lds + j * kPairStride);
-    const f2 X = q[0], Y = q[1], Z = q[2];
-    const f2 C = fma2(q[7], ca, cb);
-    const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
-    const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
-    const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
-    const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
-    const f2 w2 = w * w;
-    const f2 dL = fma2(nthr2f, w2, fma2(dx, dx, dy * dy));   // lhs - rhs, left camera
-    const f2 TL = fma2(aT, w2, C);
-    bool in0, in1, ok0, ok1;
-    if (RECT) {
-      const f2 xr = x - h.cR;
-      const f2 dxr = fma2(q[5], w, -xr), dyr = fma2(q[6], w, -y);
-      const f2 dR = fma2(nthr2f, w2, fma2(dxr, dxr, dyr * dyr));
-      // one threshold for both cameras: the larger diff decides.  fmaxf drops a NaN
-      // operand, but whatever makes one diff NaN makes T NaN or infinite as well
-      const float m0 = fmaxf(dL.x, dR.x), m1 = fmaxf(dL.y, dR.y);
-      in0 = m0 < -TL.x; in1 = m1 < -TL.y;
-      ok0 = in0 || m0 > TL.x; ok1 = in1 || m1 > TL.y;
-    } else {
-      const f2 xr = fma2(splat(h.PR[0]), X, fma2(splat(h.PR[1]), Y, fma2(splat(h.PR[2]), Z, splat(h.PR[3]))));
-      const f2 yr = fma2(splat(h.PR[4]), X, fma2(splat(h.PR[5]), Y, fma2(splat(h.PR[6]), Z, splat(h.PR[7]))));
-      const f2 wr = fma2(splat(h.PR[8]), X, fma2(splat(h.PR[9]), Y, fma2(splat(h.PR[10]), Z, splat(h.PR[11]))));
-      const f2 dxr = fma2(q[5], wr, -xr), dyr = fma2(q[6], wr, -yr);
-      const f2 wr2 = wr * wr;
-      const f2 dR = fma2(nthr2f, wr2, fma2(dxr, dxr, dyr * dyr));
-      const f2 TR = fma2(aT, wr2, C);
-      in0 = dL.x < -TL.x && dR.x < -TR.x; in1 = dL.y < -TL.y && dR.y < -TR.y;
-      // decided: surely inside both cameras, or surely outside one of them
-      ok0 = in0 || dL.x > TL.x || dR.x > TR.x; ok1 = in1 || dL.y > TL.y || dR.y > TR.y;
-    }
-    const bool has1 = 2 * j + 1 < cnt;
-    ok1 = ok1 || !has1;
-    if (!(ok0 && ok1)) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        if (k == 0 ? ok0 : ok1) continue;
-        const float *f = lds + j * kPairStride + k;
-        const double Xd = (double)f[0], Yd = (double)f[2], Zd = (double)f[4];
-        bool in = inlier_one_camera(PL, Xd, Yd, Zd, (double)f[6], (double)f[8], thr, thr2);
-        if (RECT) {
-          // P_right is P_left with another [3] (as numbers: [7] and [11] carry 0 * (t_x + tx)
-          // on top, which is not 0 only when t_x + tx is not finite; then P_right[3] is not
-          // finite either, the right x is infinite or NaN and the point is no inlier), so
-          // P_right[3] is all of it that stays live through the loop
-          const double Pr[12] = {PL[0], PL[1], PL[2],  PR[3], PL[4], PL[5],
-                                 PL[6], PL[7], PL[8], PL[9], PL[10], PL[11]};
-          in = in && fabs(PR[3]) <= 1.7976931348623157e308 &&
-               inlier_one_camera(Pr, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
-        } else {
-          in = in && inlier_one_camera(PR, Xd, Yd, Zd, (double)f[10], (double)f[12], thr, thr2);
-        }
-        if (k == 0) in0 = in; else in1 = in;
-      }
-    }
-    c += (in0 ? 1 : 0) + ((has1 && in1) ? 1 : 0);
+  const int full = cnt >> 1;          // pairs of two real points
+  const int fast = full & ~1;         // pairs the two-at-a-time loop covers
+  unsigned long long noted = 0ull;    // wave-uniform, scalar registers
+  for (int j = 0; j < fast; j += 2) {
+    bool a_in0, a_in1, b_in0, b_in1;
+    unsigned long long a_open0, a_open1, b_open0, b_open1;
+    screen_pair<RECT>(lds + j * kPairStride, h, nthr2f, aT, ca, cb, a_in0, a_in1, a_open0, a_open1);
+    screen_pair<RECT>(lds + (j + 1) * kPairStride, h, nthr2f, aT, ca, cb, b_in0, b_in1, b_open0, b_open1);
+    c += (a_in0 ? 1 : 0) + (a_in1 ? 1 : 0) + (b_in0 ? 1 : 0) + (b_in1 ? 1 : 0);
+    // population counts of lane masks: scalar instructions
+    const unsigned na = __builtin_popcountll(a_open0 | a_open1), nb = __builtin_popcountll(b_open0 | b_open1);
+    noted |= ((unsigned long long)(na < 1u ? na : 1u) | ((unsigned long long)(nb < 1u ? nb : 1u) << 1)) << j;
+  }
+  // not counted yet: the last pair of an odd number of pairs, and the last, single point of an
+  // odd number of points (the second lane of its record is a copy)
+  unsigned long long late = 0ull;
+  if (full & 1) late |= 1ull << fast;
+  if (cnt & 1) late |= 1ull << full;
+  noted |= late;
+  while (noted) {
+    const int j = __builtin_ctzll(noted);
+    noted &= noted - 1ull;
+    bool in0, in1;
+    unsigned long long open0, open1;
+    screen_pair<RECT>(lds + j * kPairStride, h, nthr2f, aT, ca, cb, in0, in1, open0, open1);
+    const bool two = j < full;
+    const unsigned long long me = 1ull << __lane_id();
+    if ((late >> j) & 1ull) c += (in0 ? 1 : 0) + ((two && in1) ? 1 : 0);
+    if (open0 & me) c += exact(lds + j * kPairStride) ? 1 : 0;
+    if (two && (open1 & me)) c += exact(lds + j * kPairStride + 1) ? 1 : 0;
   }
   return c;
+}
+
+// The same with the fp64 projections at hand.
+template <bool RECT>
+__device__ __forceinline__ int count_chunk_inliers_screened(const float *__restrict__ lds, int cnt,
+                                                            const double (&PL)[12],
+                                                            const double (&PR)[12], const Hyp32 &h,
+                                                            Screen32 sc, double thr, double thr2) {
+  return count_chunk_inliers_screened<RECT>(lds, cnt, h, sc, thr2, [&](const float *f) {
+    return inlier_exact_staged<RECT>(f, PL, PR, thr, thr2);
+  });
 }
 
 }  // namespace slamhip_dev

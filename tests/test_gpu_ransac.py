@@ -203,8 +203,8 @@ def test_packed_fp32_screening_never_changes_a_count(kind):
     return identical counts.  The scene is built to stress the bound: measurements
     placed exactly on, and a few ulps either side of, the threshold circle of the
     true pose; near (2 m) and far (400 m) points; points behind the camera and at
-    w ~ 0; hypotheses from exact to wild, including NaN, infinity and a translation
-    whose projection overflows fp64."""
+    w ~ 0; hypotheses from exact to wild, including NaN, infinity, a translation
+    whose projection overflows fp64, and finite poses with |t| from 1e-200 to 1e200."""
     from slam_amd import kernels, _lib
     from slam_amd.utils.synth import perturbed_hypotheses
     cam = _screen_camera(kind)
@@ -234,7 +234,15 @@ def test_packed_fp32_screening_never_changes_a_count(kind):
     Rts[3] *= 1e6                                   # overflows fp32 squares
     Rts[4, 0, 3] = -1.7e308                         # fx * t_x overflows fp64
     Rts[5, 0, 3] = np.inf
-    valid[:6] = 1
+    # finite poses of absurd size, as a minimal sample with a repeated pixel produces them: the
+    # screen sees the matrices scaled by a power of two, so these are decided in fp32 as well
+    for k, size in zip(range(6, 11), (1e7, 1e16, 1e31, 1e200, 1e-200)):
+        Rts[k] = Rt
+        Rts[k, :, 3] = np.array([0.3, -0.1, 1.0]) * size
+    Rts[11] = Rt * 1e-300                           # every entry tiny: scaled up instead
+    Rts[12] = Rt
+    Rts[12, :, 3] *= 1e5                            # the true direction, far out
+    valid[:13] = 1
     try:
         assert _lib.lib.slamhip_tune(2, 0) == 0
         ref = kernels.ransac_score(X, mL, mR, Rts, valid, cam.K, cam.M_right, thr).cpu().numpy()
