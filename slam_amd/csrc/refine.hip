@@ -20,10 +20,35 @@ constexpr int kRefThreads = 256;
 
 struct Intr { double K[9]; };
 
+// Sum over the 64 lanes of a wavefront, the same value in every lane.  Within a row of 16
+// lanes through DPP (two 32-bit moves per step: a few cycles each, where a shuffle through
+// LDS hardware costs a round trip per step, 28 sums x 6 steps per pass); the four row sums
+// through scalar registers.
+__device__ __forceinline__ double dpp_add(double v, int ctrl) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  int olo, ohi;
+  switch (ctrl) {   // the control word is an immediate
+    case 0: olo = __builtin_amdgcn_update_dpp(0, lo, 0xB1, 0xF, 0xF, true);
+            ohi = __builtin_amdgcn_update_dpp(0, hi, 0xB1, 0xF, 0xF, true); break;   // lanes 1,0,3,2
+    case 1: olo = __builtin_amdgcn_update_dpp(0, lo, 0x4E, 0xF, 0xF, true);
+            ohi = __builtin_amdgcn_update_dpp(0, hi, 0x4E, 0xF, 0xF, true); break;   // lanes 2,3,0,1
+    case 2: olo = __builtin_amdgcn_update_dpp(0, lo, 0x141, 0xF, 0xF, true);
+            ohi = __builtin_amdgcn_update_dpp(0, hi, 0x141, 0xF, 0xF, true); break;  // half-row mirror
+    default: olo = __builtin_amdgcn_update_dpp(0, lo, 0x140, 0xF, 0xF, true);
+             ohi = __builtin_amdgcn_update_dpp(0, hi, 0x140, 0xF, 0xF, true); break; // row mirror
+  }
+  return v + __hiloint2double(ohi, olo);
+}
+__device__ __forceinline__ double read_lane(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
+  v = dpp_add(v, 0);
+  v = dpp_add(v, 1);
+  v = dpp_add(v, 2);
+  v = dpp_add(v, 3);
+  return (read_lane(v, 0) + read_lane(v, 16)) + (read_lane(v, 32) + read_lane(v, 48));
 }
 
 // exp of a rotation vector (Rodrigues), row-major 3x3
@@ -47,28 +72,32 @@ __device__ bool solve_damped(const double *h, const double *g, double lambda, do
   for (int i = 0; i < 6; ++i)
     for (int j = i; j < 6; ++j) { A[i][j] = h[k]; A[j][i] = h[k]; ++k; }
   for (int i = 0; i < 6; ++i) A[i][i] += lambda * fmax(A[i][i], 1e-12);
-  double L[6][6];
+  // Cholesky with the reciprocal of each pivot's root kept (one reciprocal square root per
+  // row in place of a root and a division per entry below it: this runs in one lane, and
+  // its 27 divisions were a third of a refinement pass)
+  double L[6][6], inv[6];
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j <= i; ++j) {
       double s = A[i][j];
       for (int m = 0; m < j; ++m) s -= L[i][m] * L[j][m];
       if (i == j) {
         if (!(s > 0.0)) return false;
-        L[i][i] = sqrt(s);
+        inv[i] = rsqrt(s);
+        L[i][i] = s * inv[i];
       } else {
-        L[i][j] = s / L[j][j];
+        L[i][j] = s * inv[j];
       }
     }
   double y[6];
   for (int i = 0; i < 6; ++i) {
     double s = -g[i];
     for (int m = 0; m < i; ++m) s -= L[i][m] * y[m];
-    y[i] = s / L[i][i];
+    y[i] = s * inv[i];
   }
   for (int i = 5; i >= 0; --i) {
     double s = y[i];
     for (int m = i + 1; m < 6; ++m) s -= L[m][i] * x[m];
-    x[i] = s / L[i][i];
+    x[i] = s * inv[i];
   }
   return true;
 }
