@@ -62,8 +62,8 @@ const char *slamhip_strerror(int code);
  * three rounds of 256 hypotheses and the rest of the cap as one merged launch; 1 always
  * rounds of 256; 2 rounds with the merged tail whatever the pair count; identical results;
  * set it before sizing a workspace), knob 5 = sort
- * algorithm (0 auto, 1 rank counting, 2 bitonic network where the segments fit it;
- * same order), knob 6 / 7 = matrix-core matcher: blocks a launch aims at / train rows
+ * algorithm (0 auto: radix passes in LDS where the segments fit, 1 rank counting, 2 bitonic
+ * network where the segments fit it; same order), knob 6 / 7 = matrix-core matcher: blocks a launch aims at / train rows
  * per block it does not exceed when blocks abound (0 = default), knob 8 = where the
  * matrix-core matcher folds its train splits (2, the default: inside the launch for small
  * calls, a merge launch for large ones; 1: always inside; 0: always a merge launch; set it

@@ -554,6 +554,99 @@ __global__ __launch_bounds__(T) void bitonic_sort_kernel(const int32_t *__restri
 }
 
 // ---------------------------------------------------------------------------
+// The same order by a stable least-significant-digit radix sort in LDS: the distance field of
+// the key has 11 bits, so two passes over 6-bit digits order the segment (equal distances stay
+// in index order, which is the order they start in).  A pass: every wavefront takes chunks of
+// 64 keys; the lanes of a chunk that hold the same digit find each other with one ballot per
+// digit bit, which gives a key's rank among them and their number -- noted per (digit, chunk);
+// an exclusive scan over those counts in (digit, chunk) order turns them into positions.  Ten
+// barriers per segment where the bitonic network has log2(N) (log2(N) + 1) / 2 + 2 = 68 for
+// 1500 keys, and work that grows with n, not n log^2 n.  One block per segment.
+// CAP = keys the block's LDS holds: 2 x CAP keys (ping-pong) + 64 x CAP / 64 16-bit counts.
+// ---------------------------------------------------------------------------
+template <int T, int CAP>
+__global__ __launch_bounds__(T) void radix_sort_kernel(const int32_t *__restrict__ dist, int dist_stride,
+                                                       int n_single, const int32_t *__restrict__ off,
+                                                       const int32_t *__restrict__ cnt,
+                                                       int32_t *__restrict__ order) {
+  constexpr int W = T / 64;
+  __shared__ uint32_t keys[2][CAP];
+  __shared__ uint16_t counts[CAP];        // [digit][chunk], chunks = ceil(n / 64) <= CAP / 64
+  __shared__ uint32_t wave_total[W];
+  const int seg = blockIdx.x;
+  int s0 = 0, n = n_single;
+  if (off != nullptr) {
+    s0 = off[seg];
+    n = cnt ? cnt[seg] : off[seg + 1] - s0;
+  }
+  if (n <= 0 || n > CAP) return;   // block-uniform; longer segments are not this kernel's (launch_sort)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunks = (n + 63) >> 6, entries = chunks << 6;
+  for (int i = threadIdx.x; i < n; i += T) {
+    const int d = dist[(size_t)(s0 + i) * dist_stride];
+    keys[0][i] = ((d < 0 ? 2047u : (uint32_t)d) << kKeyShift) | (uint32_t)i;
+  }
+  // digit of the key at position c * 64 + lane, its rank among the chunk's keys with that digit,
+  // and how many those are
+  auto classify = [&](const uint32_t *src, int c, int shift, uint32_t &key, int &digit, int &rank, int &same) {
+    const int e = (c << 6) + lane;
+    const bool valid = e < n;
+    key = valid ? src[e] : 0u;
+    digit = (int)((key >> shift) & 63u);
+    unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const bool bit = (digit >> b) & 1;
+      const unsigned long long has = __builtin_amdgcn_ballot_w64(bit);
+      peers &= bit ? has : ~has;
+    }
+    rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+    same = __builtin_popcountll(peers);
+    return valid;
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t *src = keys[pass];
+    uint32_t *dst = keys[pass ^ 1];
+    const int shift = kKeyShift + 6 * pass;
+    for (int i = threadIdx.x; i < entries; i += T) counts[i] = 0;
+    __syncthreads();   // also: the keys of the previous step are all written
+    for (int c = wave; c < chunks; c += W) {
+      uint32_t key; int digit, rank, same;
+      if (classify(src, c, shift, key, digit, rank, same) && rank == 0)
+        counts[digit * chunks + c] = (uint16_t)same;
+    }
+    __syncthreads();
+    // exclusive scan of counts[0 .. entries): a run per thread, the runs' totals over the block
+    const int per = (entries + T - 1) / T;
+    const int b0 = min((int)threadIdx.x * per, entries), b1 = min(b0 + per, entries);
+    uint32_t mine = 0;
+    for (int i = b0; i < b1; ++i) mine += counts[i];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t running = incl - mine;
+    for (int w = 0; w < wave; ++w) running += wave_total[w];
+    for (int i = b0; i < b1; ++i) {
+      const uint32_t v = counts[i];
+      counts[i] = (uint16_t)running;
+      running += v;
+    }
+    __syncthreads();
+    for (int c = wave; c < chunks; c += W) {
+      uint32_t key; int digit, rank, same;
+      if (classify(src, c, shift, key, digit, rank, same)) dst[counts[digit * chunks + c] + rank] = key;
+    }
+    __syncthreads();
+  }
+  for (int r = threadIdx.x; r < n; r += T) order[s0 + r] = (int32_t)(keys[0][r] & kIdxMask);
+}
+
+// ---------------------------------------------------------------------------
 // Stable order by (distance, query index) through rank counting: the keys
 // (dist << 21 | index) are unique, so rank(i) = #{j : key_j < key_i} and the
 // sorted sequence is order[rank(i)] = i.  2 VALU ops per (i, j) pair, all j
@@ -649,7 +742,7 @@ int g_prof_repeat = 1;     // knob 10: launches of the top-2 kernel per probed c
 int g_raw_rows = 1;        // knob 9: matrix-core kernel reads unpacked rows itself (0 = packing launch first)
 int g_fold_in_kernel = 2;  // knob 8: 0 = always the separate merge launch, 1 = never, 2 = by size
 int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
-int g_force_sort = 0;      // 0 auto, 1 rank counting, 2 bitonic network (where it fits)
+int g_force_sort = 0;      // 0 auto (radix passes where the segment fits LDS), 1 rank counting, 2 bitonic network
 
 MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                     int desc_bytes, long long n_out = -1, bool prepacked = false,
@@ -925,9 +1018,9 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   return SLAMHIP_OK;
 }
 
-// Stable sort of every segment by (distance, index): LDS bitonic network (one block
-// per segment; 1024 threads when the segments are few and long) when the segments fit
-// it, rank counting (many blocks per segment) for longer ones.
+// Stable sort of every segment by (distance, index): radix passes in LDS (one block per
+// segment; 1024 threads when the segments are few and long) when the segments fit, rank
+// counting (many blocks per segment) for longer ones; knob 5 = 2 keeps the bitonic network.
 void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int32_t *d_off,
                  const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order, hipStream_t st) {
   // Measured: 500 segments of 1500 rows 30 us by the network (256 threads) against 60 by
@@ -935,7 +1028,21 @@ void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int
   // 1024-thread network against 1.03 ms with rank counting.
   bool bitonic = max_n <= kBitonicMax;
   if (g_force_sort == 1) bitonic = false;
-  if (bitonic) {
+  // 500 segments of 1500 rows: 40 us by the network, 16 by the radix passes (700 rows: 20 / 9);
+  // two frames of 8000 features, the whole front-end call: 0.27 / 0.21 ms.  The radix kernel
+  // takes every segment that fits its LDS unless knob 5 says otherwise.
+  if (bitonic && g_force_sort != 2) {
+    if (max_n <= 2048) {
+      hipLaunchKernelGGL((radix_sort_kernel<256, 2048>), dim3(n_segments), dim3(256), 0, st, d_dist, dist_stride,
+                         n_single, d_off, d_cnt, d_order);
+    } else if (n_segments >= 128) {
+      hipLaunchKernelGGL((radix_sort_kernel<256, kBitonicMax>), dim3(n_segments), dim3(256), 0, st, d_dist,
+                         dist_stride, n_single, d_off, d_cnt, d_order);
+    } else {
+      hipLaunchKernelGGL((radix_sort_kernel<1024, kBitonicMax>), dim3(n_segments), dim3(1024), 0, st, d_dist,
+                         dist_stride, n_single, d_off, d_cnt, d_order);
+    }
+  } else if (bitonic) {
     int N = 1;
     while (N < max_n) N <<= 1;
     if (n_segments >= 128 || N <= 1024)

@@ -282,7 +282,8 @@ def test_ratio_test_and_sort_and_cross_check():
     np.testing.assert_array_equal(md.cpu().numpy(), ed)
 
 
-@pytest.mark.parametrize("force_sort", [0, 1])      # tune knob 5: 0 = auto (network where it fits), 1 = rank counting
+# tune knob 5: 0 = auto (radix passes in LDS where the segment fits), 1 = rank counting, 2 = bitonic network
+@pytest.mark.parametrize("force_sort", [0, 1, 2])
 def test_sort_large_and_segmented(force_sort):
     from slam_amd import _lib, kernels
     _lib.lib.slamhip_tune(5, force_sort)
@@ -297,8 +298,9 @@ def test_sort_large_and_segmented(force_sort):
     o = kernels.sort_by_distance(dd, off=off).cpu().numpy()
     for s in range(len(sizes)):
         np.testing.assert_array_equal(o[off[s]:off[s + 1]], so.sort_by_distance(dd[off[s]:off[s + 1]]))
-    # single segments (network with 1024 threads up to 8192 rows, rank counting beyond): powers of two and their neighbours, absent distances (-1)
-    for n in (1, 2, 3, 255, 256, 257, 4097, 8191, 8192, 8193):
+    # single segments (LDS kernels up to 8192 rows, rank counting beyond): powers of two, chunk
+    # boundaries and their neighbours, absent distances (-1)
+    for n in (1, 2, 3, 63, 64, 65, 255, 256, 257, 2047, 2048, 2049, 4097, 8191, 8192, 8193):
         d = rng.integers(0, 12, n).astype(np.int32)
         d[rng.random(n) < 0.05] = -1
         np.testing.assert_array_equal(kernels.sort_by_distance(d).cpu().numpy(), so.sort_by_distance(d),
