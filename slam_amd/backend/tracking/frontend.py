@@ -332,7 +332,7 @@ class TrackingFrontend:
         # the outputs that must start at zero share one allocation (one fill launch
         # instead of five: the one-pair online call is bounded by its launches)
         P = max(F - 1, 1)
-        zsizes = (("st_desc", torch.int32, max(NL * W, 1)), ("pose_ransac", torch.float64, P * 12),
+        zsizes = (("pose_ransac", torch.float64, P * 12),
                   ("pose_refined", torch.float64, P * 12), ("ransac_info", torch.int32, P * 8),
                   ("tm_mask", torch.uint8, max(NL, 1)))
         offs, total = [], 0
@@ -344,6 +344,9 @@ class TrackingFrontend:
             "st_count": i32(F), "st_left": i32(NL), "st_right": i32(NL), "st_dist": i32(NL),
             "st_xyz": f32(NL * 3), "st_pix_left": f32(NL * 2), "st_pix_right": f32(NL * 2),
             "tm_query": i32(NL), "tm_train": i32(NL), "tm_dist": i32(NL),
+            # rows [off_left[f], +st_count[f]) of each frame are written, whole packed rows; the
+            # rest is never read (64 bytes per feature: not worth a fill launch per call)
+            "st_desc": i32(NL * W),
         }
         for (name, dt, n), o in zip(zsizes, offs):
             t[name] = zbuf[o:o + n * torch.empty(0, dtype=dt).element_size()].view(dt)

@@ -62,12 +62,13 @@ def test_500_frames_of_1500_features():
     info = h["ransac_info"].reshape(-1, 8)[:F - 1]
     off = inputs.off_left
     # run-to-run determinism: the arrays that start at zero whole, the others over the rows in use
-    for k in ("st_count", "ransac_info", "pose_ransac", "pose_refined", "tm_mask", "st_desc"):
+    for k in ("st_count", "ransac_info", "pose_ransac", "pose_refined", "tm_mask"):
         np.testing.assert_array_equal(h[k], again[k], err_msg=k)
     used_st = np.concatenate([np.arange(off[f], off[f] + h["st_count"][f]) for f in range(F)])
     used_tm = np.concatenate([np.arange(off[p], off[p] + info[p, 5]) for p in range(F - 1)])
     for k, rows, w in (("st_left", used_st, 1), ("st_right", used_st, 1), ("st_dist", used_st, 1),
                        ("st_xyz", used_st, 3), ("st_pix_left", used_st, 2), ("st_pix_right", used_st, 2),
+                       ("st_desc", used_st, h["st_desc"].size // len(h["st_left"])),
                        ("tm_query", used_tm, 1), ("tm_train", used_tm, 1), ("tm_dist", used_tm, 1)):
         np.testing.assert_array_equal(h[k].reshape(-1, w)[rows], again[k].reshape(-1, w)[rows], err_msg=k)
     assert (h["st_count"][:F] == st_count).all() and st_count.min() > 400
