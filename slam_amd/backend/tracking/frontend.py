@@ -354,7 +354,11 @@ class TrackingFrontend:
         a.n_frames, a.n_left_total, a.n_right_total = F, NL, NR
         a.max_left = int(np.diff(inp.off_left).max()) if F else 0
         a.max_right = int(np.diff(inp.off_right).max()) if F else 0
-        a.desc_bytes = a.desc_stride = D
+        # rows may lie in a wider buffer (e.g. 64-byte slots for 61-byte descriptors: aligned loads)
+        if inp.des_left.stride(1) != 1 or inp.des_right.stride(1) != 1 or \
+                (NR > 0 and inp.des_right.stride(0) != inp.des_left.stride(0)):
+            raise ValueError("descriptor rows must be contiguous and both arrays must have one row stride")
+        a.desc_bytes, a.desc_stride = D, int(inp.des_left.stride(0))
         a.d_kp_left, a.d_kp_right = inp.kp_left.data_ptr(), inp.kp_right.data_ptr()
         a.d_des_left, a.d_des_right = inp.des_left.data_ptr(), inp.des_right.data_ptr()
         a.d_off_left, a.d_off_right = inp.d_off_left.data_ptr(), inp.d_off_right.data_ptr()

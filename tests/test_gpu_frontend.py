@@ -598,6 +598,19 @@ def test_frontend_reads_descriptor_rows_in_place(nbytes, cross):
         assert x.keys() == y.keys()
         for k in x:
             np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+    # the same rows lying in wider slots (row stride 80, whatever fills the gaps)
+    import torch
+    dl, dr = inp.des_left, inp.des_right
+    wide_l = torch.full((dl.shape[0], 80), 0xA5, dtype=torch.uint8, device=dl.device)
+    wide_r = torch.full((dr.shape[0], 80), 0x5A, dtype=torch.uint8, device=dr.device)
+    wide_l[:, :nbytes], wide_r[:, :nbytes] = dl, dr
+    inp.des_left, inp.des_right = wide_l[:, :nbytes], wide_r[:, :nbytes]
+    fe._ws = None
+    c, _ = snapshot()
+    inp.des_left, inp.des_right = dl, dr
+    for x, y in zip(a, c):
+        for k in x:
+            np.testing.assert_array_equal(x[k], y[k], err_msg="strided " + k)
     # the packed inlier descriptor rows the temporal matcher reads, zero padding included
     W = 8 if nbytes <= 32 else 16
     da, db = ha["st_desc"].reshape(-1, W), hb["st_desc"].reshape(-1, W)
