@@ -110,6 +110,17 @@ def test_frontend_device_sampler_and_edge_cases():
     # single frame: stereo stage only
     r1 = fe.run(frames[:1])
     assert len(r1.frame(0)["left_idx"]) > 50
+    # no right features at all; frames of one to five features (fewer rows than one 16-byte load
+    # of the in-place reader per array is the library's business, not the caller's)
+    none_right = [(f[0], np.zeros((0, 2), np.float32), f[2], np.zeros((0, 61), np.uint8)) for f in frames[:3]]
+    r = fe.run(none_right)
+    assert not r.to_host()["st_count"][:3].any() and r.pair(1)["n_matches"] == 0
+    tiny = [tuple(a[:k] for a in frames[i]) for i, k in enumerate((1, 2, 3, 5))]
+    r = fe.run(tiny)
+    h = r.to_host()
+    assert (h["st_count"][:4] <= np.array([1, 2, 3, 5])).all()
+    for p in range(3):
+        assert r.pair(p)["n_matches"] <= h["st_count"][p] and r.pair(p)["best_index"] == -1   # < 4 points: not attempted
 
 
 def _shard_worker(rank, world, port, q):
