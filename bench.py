@@ -184,7 +184,7 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
             sharding.gather_records(blob, dst=0)
         return res
 
-    for _ in range(2):
+    for _ in range(5):       # a pass is well under a millisecond: a few of them before the clock is read
         res = step()
     torch.cuda.synchronize()
     if dist is not None:
@@ -459,7 +459,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=500,
                     help="frames per GPU of the secondary front-end measurement (0 = skip)")
-    ap.add_argument("--frontend-steps", type=int, default=5)
+    ap.add_argument("--frontend-steps", type=int, default=20)
     ap.add_argument("--envelope-frames", type=int, default=60,
                     help="frames of the 2000-8000 features/image front-end measurement (0 = skip)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the matcher size sweep")
