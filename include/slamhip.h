@@ -71,7 +71,10 @@ const char *slamhip_strerror(int code);
  * caller's rows as they are (1, the default) or rows packed by a launch in front (0), knob 10 =
  * launches of the top-2 kernel per call while the duration probe below is on (1..64, default 1:
  * identical launches back to back between the probe's two events, which spreads the events' own
- * cost; slamhip_profile_end then reports the time of all of them).  Process-global; not
+ * cost; slamhip_profile_end then reports the time of all of them), knob 11 = batched launches
+ * of the matrix-core matcher (64 pairs or more) deal their blocks to the chip's eight XCDs pair
+ * by pair, so that a pair's rows come into one L2 (1, the default), or use the plain grid (0);
+ * same results.  Process-global; not
  * for use while other threads are inside the library. */
 int slamhip_tune(int knob, int value);
 

@@ -41,6 +41,9 @@ extern int g_ransac_screen;
 // pairs; three rounds and a merged tail for the front-end's long calls), 1 = always rounds
 // of 256 hypotheses, 2 = rounds with the merged tail.  Set through slamhip_tune(4, value).
 extern int g_ransac_mode;
+// 1 (default): batched matrix-core matcher launches deal their blocks to the XCDs pair by pair;
+// 0: plain three-dimensional grid.  Set through slamhip_tune(11, value).
+extern int g_xcd_remap;
 
 // splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
     const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
     uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2,
     unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep, int row_stride, int desc_bytes,
-    const uint8_t *__restrict__ q_end, const uint8_t *__restrict__ t_end) {
+    const uint8_t *__restrict__ q_end, const uint8_t *__restrict__ t_end, int xq, int xs, int xp) {
   using GEO = Geo<W, NW>;
   constexpr int kThreads = GEO::NT;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
@@ -169,7 +169,22 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
   __shared__ uint4 lds[2 * kStageSlots + 2 * kThreads / 4];
   float *ctab = reinterpret_cast<float *>(lds + 2 * kStageSlots);
 
-  const int pair = blockIdx.z;
+  // Which (query block, split, pair) this block is.  Plain: the grid's three dimensions.  With
+  // xq > 0 the grid is one-dimensional and blocks are dealt to the chip's eight XCDs by hand: the
+  // hardware hands consecutive workgroups to consecutive XCDs, each with an L2 of its own, so
+  // block id -> XCD id % 8, and every block of a pair (all query blocks, all splits) is given an
+  // id of the same residue -- the pair's train rows then come into ONE L2 once instead of into
+  // as many as the pair has query blocks (xq query blocks x xs splits x xp pairs; pairs are dealt
+  // round-robin to the XCDs, ids whose pair does not exist leave at once).
+  int pair = blockIdx.z, bx = blockIdx.x, split = blockIdx.y, n_splits = gridDim.y;
+  if (xq > 0) {
+    const int id = blockIdx.x, j = id >> 3;
+    bx = j % xq;
+    split = (j / xq) % xs;
+    pair = (j / (xq * xs)) * 8 + (id & 7);
+    n_splits = xs;
+    if (pair >= xp) return;   // block-uniform
+  }
   int q0 = 0, nq = nq_single, t0 = 0, nt = nt_single;
   if (q_off != nullptr) {
     q0 = q_off[pair];
@@ -178,11 +193,9 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
     nt = t_cnt ? t_cnt[pair] : t_off[pair + 1] - t0;
   }
   const int o0 = out_off ? out_off[pair] : q0;
-  const int qblk = blockIdx.x * (NW * 32 * G);
+  const int qblk = bx * (NW * 32 * G);
   if (qblk >= nq) return;  // block-uniform
 
-  const int n_splits = gridDim.y;
-  const int split = blockIdx.y;
   // whole tiles per split; the host keeps a split within MASK + 1 rows
   int rps = (nt + n_splits - 1) / n_splits;
   rps = (rps + 31) & ~31;
@@ -456,7 +469,7 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's key pairs have left
     __syncthreads();                                      // ... and every other wave's of the block
     int *const last_flag = reinterpret_cast<int *>(lds);  // the stage buffers are no longer read
-    unsigned *const cnt = arrivals + (size_t)pair * gridDim.x + blockIdx.x;
+    unsigned *const cnt = arrivals + (size_t)pair * gridDim.x + blockIdx.x;   // plain grid only (launch())
     if (tid == 0) {
       const unsigned before = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       last_flag[0] = before == (unsigned)(n_splits - 1);
@@ -521,14 +534,23 @@ void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, c
             const int32_t *q_cnt, const int32_t *t_off, const int32_t *t_cnt, const int32_t *out_off,
             int nq, int nt, int nq_total, uint2 *part, int32_t *idx2, int32_t *dist2, unsigned *arrivals,
             double ratio, uint8_t *keep, const slamhip_internal::RawRows *raw) {
+  // Batches of pairs with several blocks each: blocks dealt to the XCDs pair by pair (see the
+  // kernel).  A single pair keeps the plain grid (its query blocks, grid.x, are a multiple of
+  // eight where it matters, so blocks that share queries already share an XCD), and so does the
+  // fold inside the kernel, whose counters are indexed by the plain grid.
+  int xq = 0, xs = 0, xp = 0;
+  if (grid.z >= 64 && grid.x * grid.y > 1 && arrivals == nullptr && slamhip_internal::g_xcd_remap != 0) {
+    xq = (int)grid.x; xs = (int)grid.y; xp = (int)grid.z;
+    grid = dim3(grid.x * grid.y * ((grid.z + 7) / 8 * 8), 1, 1);
+  }
   if (raw != nullptr)
     hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, true>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,
                        q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep,
-                       raw->row_stride, raw->desc_bytes, raw->q_end, raw->t_end);
+                       raw->row_stride, raw->desc_bytes, raw->q_end, raw->t_end, xq, xs, xp);
   else
     hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, false>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,
                        q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep, 0,
-                       0, nullptr, nullptr);
+                       0, nullptr, nullptr, xq, xs, xp);
 }
 
 }  // namespace

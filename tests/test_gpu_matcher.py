@@ -256,6 +256,46 @@ def test_batched_ragged_pairs():
         np.testing.assert_array_equal(d[q_off[p]:q_off[p + 1]], ed, err_msg=f"pair {p}")
 
 
+@pytest.mark.parametrize("n_pairs", [64, 67, 150])
+@pytest.mark.parametrize("nbytes", [61, 32])
+def test_many_ragged_pairs_dealt_to_the_xcds(n_pairs, nbytes):
+    """Launches of 64 pairs or more deal the matrix-core matcher's blocks to the XCDs pair by pair
+    (one-dimensional grid, (pair, split, query block) derived from the block id; ids of pairs that
+    do not exist leave at once): pair counts that are and are not a multiple of eight, pairs of
+    zero to several query blocks and stages, splits forced and not -- equal to the oracle and to
+    the plain grid (tune knob 11 = 0)."""
+    from slam_amd import kernels, _lib
+    rng = np.random.default_rng(n_pairs + nbytes)
+    nqs = [int(v) for v in rng.choice([0, 1, 31, 130, 257, 600], n_pairs)]
+    nts = [int(v) for v in rng.choice([0, 1, 33, 129, 300, 700], n_pairs)]
+    qs = [rng.integers(0, 256, (n, nbytes), dtype=np.uint8) for n in nqs]
+    ts = [rng.integers(0, 256, (n, nbytes), dtype=np.uint8) for n in nts]
+    for p in range(0, n_pairs, 5):            # ties: duplicated train rows
+        if nts[p] > 40:
+            ts[p][20:40] = ts[p][0:20]
+    q_off = np.concatenate([[0], np.cumsum(nqs)]).astype(np.int32)
+    t_off = np.concatenate([[0], np.cumsum(nts)]).astype(np.int32)
+    q, t = np.vstack(qs), np.vstack(ts)
+    try:
+        for splits in (0, 3):
+            _lib.lib.slamhip_tune(1, splits)
+            got = {}
+            for dealt in (1, 0):
+                _lib.lib.slamhip_tune(11, dealt)
+                i, d = kernels.hamming_knn2_batched(q, t, q_off, t_off)
+                got[dealt] = (i.cpu().numpy(), d.cpu().numpy())
+            np.testing.assert_array_equal(got[1][0], got[0][0])
+            np.testing.assert_array_equal(got[1][1], got[0][1])
+    finally:
+        _lib.lib.slamhip_tune(1, 0)
+        _lib.lib.slamhip_tune(11, 1)
+    i, d = got[1]
+    for p in range(n_pairs):
+        ei, ed = so.hamming_knn2(qs[p], ts[p])
+        np.testing.assert_array_equal(i[q_off[p]:q_off[p + 1]], ei, err_msg=f"pair {p}")
+        np.testing.assert_array_equal(d[q_off[p]:q_off[p + 1]], ed, err_msg=f"pair {p}")
+
+
 def test_ratio_test_and_sort_and_cross_check():
     from slam_amd import kernels
     from slam_amd.utils.synth import matcher_workload
