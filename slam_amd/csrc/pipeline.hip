@@ -575,11 +575,16 @@ __device__ __forceinline__ void ransac_count_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32) {
+    const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32,
+    int n_pairs) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
-  const int p = blockIdx.z;
-  ransac_count_item<MODE>(lds, p, (size_t)p * slots + blockIdx.y / (kHypPerRound / 64),
-                          (int)(blockIdx.y % (kHypPerRound / 64)), blockIdx.x * (chunks_per_span * kPtsPerChunk),
+  // grid (pairs rounded up to a multiple of 8, point spans, slots * kHypPerRound / 64): the pair is
+  // the fastest index and the hardware hands consecutive workgroups to consecutive XCDs, so all
+  // blocks of a pair run on XCD pair % 8 and its points and hypothesis tables come into one L2
+  const int p = blockIdx.x;
+  if (p >= n_pairs) return;
+  ransac_count_item<MODE>(lds, p, (size_t)p * slots + blockIdx.z / (kHypPerRound / 64),
+                          (int)(blockIdx.z % (kHypPerRound / 64)), blockIdx.y * (chunks_per_span * kPtsPerChunk),
                           chunks_per_span * kPtsPerChunk, obase, tm_count, cx, cpl, cpr, cam, thresh, rt,
                           counts, info, hyp32);
 }
@@ -594,7 +599,7 @@ __device__ __forceinline__ void ransac_count_list_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks, int slots, const float *__restrict__ hyp32,
+    const int32_t *__restrict__ info, int chunks, int slots, const float *__restrict__ hyp32, int,
     const int32_t *__restrict__ list) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   constexpr int kGroups = kHypPerRound / 64;
@@ -613,8 +618,10 @@ __device__ __forceinline__ void ransac_count_list_body(
   const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,                         \
       const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,  \
       RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,   \
-      const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32
-#define SLAMHIP_COUNT_PASS obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, chunks_per_span, slots, hyp32
+      const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32, \
+      int n_pairs
+#define SLAMHIP_COUNT_PASS \
+  obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, chunks_per_span, slots, hyp32, n_pairs
 
 __global__ __launch_bounds__(64) void ransac_count_fp64_kernel(SLAMHIP_COUNT_ARGS) {
   ransac_count_body<0>(SLAMHIP_COUNT_PASS);
@@ -794,10 +801,10 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr, hyp32);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
-      const dim3 cgrid(slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64), np);
+      const dim3 cgrid((np + 7) / 8 * 8, slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64));
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
                          prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots,
-                         (const float *)hyp32);
+                         (const float *)hyp32, np);
     }
     if (tail) {
       // replay of the last wide round (state and winner pose up to date), then every block left
@@ -812,7 +819,7 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       const long long most = (long long)np * tail * (kHypPerRound / 64) * chunks;
       hipLaunchKernelGGL(count_list, dim3((unsigned)(most < kTailGrid ? most : kTailGrid)), dim3(64), 0, st,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt_tail, counts_tail,
-                         info + 8 * (size_t)g0, chunks, tail, (const float *)nullptr, (const int32_t *)list);
+                         info + 8 * (size_t)g0, chunks, tail, (const float *)nullptr, np, (const int32_t *)list);
       hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, kWideRounds, tail,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt_tail, counts_tail,
                          pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
