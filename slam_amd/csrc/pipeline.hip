@@ -578,15 +578,18 @@ __device__ __forceinline__ void ransac_count_body(
     const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32,
     int n_pairs) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
-  // grid (pairs rounded up to a multiple of 8, point spans, slots * kHypPerRound / 64): the pair is
-  // the fastest index and the hardware hands consecutive workgroups to consecutive XCDs, so all
-  // blocks of a pair run on XCD pair % 8 and its points and hypothesis tables come into one L2
-  const int p = blockIdx.x;
-  if (p >= n_pairs) return;
-  ransac_count_item<MODE>(lds, p, (size_t)p * slots + blockIdx.z / (kHypPerRound / 64),
-                          (int)(blockIdx.z % (kHypPerRound / 64)), blockIdx.y * (chunks_per_span * kPtsPerChunk),
-                          chunks_per_span * kPtsPerChunk, obase, tm_count, cx, cpl, cpr, cam, thresh, rt,
-                          counts, info, hyp32);
+  // n_pairs > 0: grid (pairs rounded up to a multiple of 8, point spans, slots * kHypPerRound / 64):
+  // the pair is the fastest index and the hardware hands consecutive workgroups to consecutive XCDs,
+  // so all blocks of a pair run on XCD pair % 8 and its points and hypothesis tables come into one
+  // L2.  n_pairs == 0 (calls with few pairs, which dealt by pair would load the XCDs unevenly):
+  // grid (point spans, slots * kHypPerRound / 64, pairs), a pair's blocks spread over the chip.
+  const bool by_pair = n_pairs > 0;
+  const int p = by_pair ? blockIdx.x : blockIdx.z;
+  if (by_pair && p >= n_pairs) return;
+  const int span = by_pair ? blockIdx.y : blockIdx.x, gy = by_pair ? blockIdx.z : blockIdx.y;
+  ransac_count_item<MODE>(lds, p, (size_t)p * slots + gy / (kHypPerRound / 64), gy % (kHypPerRound / 64),
+                          span * (chunks_per_span * kPtsPerChunk), chunks_per_span * kPtsPerChunk, obase,
+                          tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, hyp32);
 }
 
 // The merged tail's counting launch: a fixed grid of wavefronts strides over the work the
@@ -712,6 +715,7 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
 // kHypPerRound at most) and replays them all in the finishing launch -- 3 launches
 // instead of 2 per round.  Same samples, same replay order, same outcome.
 constexpr int kMaxSlots = 16;
+constexpr int kPairsPerXcdDeal = 64;     // pairs from which the counting launch deals its blocks to the XCDs by pair
 constexpr int kTailGrid = 4096;         // wavefronts of the merged tail's counting launch: 4 per SIMD
 constexpr int kSinglePassPairs = 64;    // measured break-even against the adaptive rounds at ~40 % inliers
 
@@ -801,10 +805,14 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr, hyp32);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
-      const dim3 cgrid((np + 7) / 8 * 8, slamhip_ceil_div(chunks, per_span), slots * (kHypPerRound / 64));
+      // a pair's blocks on one XCD where there are pairs enough to load the eight evenly (measured:
+      // 499 pairs of ~600 points 59 -> 41 us per launch; 59 ragged pairs 201 -> 256 us)
+      const bool by_pair = np >= kPairsPerXcdDeal;
+      const int spans = slamhip_ceil_div(chunks, per_span), groups = slots * (kHypPerRound / 64);
+      const dim3 cgrid = by_pair ? dim3((np + 7) / 8 * 8, spans, groups) : dim3(spans, groups, np);
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
                          prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots,
-                         (const float *)hyp32, np);
+                         (const float *)hyp32, by_pair ? np : 0);
     }
     if (tail) {
       // replay of the last wide round (state and winner pose up to date), then every block left
