@@ -119,27 +119,37 @@ __global__ __launch_bounds__(kBlock) void stereo_points_kernel(
   // descriptor rows of this block's inliers, in inlier order (W is a power of two)
   const int rows = min(kBlock, m - i0);
   const int lw = W == 8 ? 3 : (W == 16 ? 4 : 5);
+  // one 16-byte chunk of a row per step (W / 4 chunks a row): few, wide, independent loads
+  const int cpr = W >> 2, lc = lw - 2;
   if (raw_left == nullptr) {
-    for (int e = threadIdx.x; e < rows * W; e += kBlock) {
-      const int r = i0 + (e >> lw), w = e & (W - 1);
-      st_desc[(size_t)(base + r) * W + w] = packed_left[(size_t)(base + st_left[base + r]) * W + w];
+    const uint4 *src = reinterpret_cast<const uint4 *>(packed_left);
+    uint4 *dst = reinterpret_cast<uint4 *>(st_desc);
+#pragma unroll 4
+    for (int e = threadIdx.x; e < rows * cpr; e += kBlock) {
+      const int r = i0 + (e >> lc), c = e & (cpr - 1);
+      dst[(size_t)(base + r) * cpr + c] = src[(size_t)(base + st_left[base + r]) * cpr + c];
     }
   } else {
-    // the caller's rows (any stride and alignment; raw_bytes >= 4): dword loads that never
-    // leave the array -- one that would is moved back to its end and shifted -- and zeros
-    // behind the descriptor's last byte, which is what a packed row holds
-    for (int e = threadIdx.x; e < rows * W; e += kBlock) {
-      const int r = i0 + (e >> lw), w = e & (W - 1);
-      const int nb = desc_bytes - 4 * w;            // descriptor bytes from this word on
-      uint32_t v = 0u;
-      if (nb > 0) {
-        const size_t at = (size_t)(base + st_left[base + r]) * raw_stride + 4 * w;
-        const size_t from = at + 4 <= raw_bytes ? at : raw_bytes - 4;
-        __builtin_memcpy(&v, raw_left + from, 4);
-        v >>= 8 * (int)(at - from);
-        if (nb < 4) v &= (1u << (8 * nb)) - 1u;
-      }
-      st_desc[(size_t)(base + r) * W + w] = v;
+    // the caller's rows (any stride and alignment; raw_bytes >= 16): 16-byte loads that never
+    // leave the array -- one that would is moved back to end at its end and shifted down -- and
+    // zeros behind the descriptor's last byte, which is what a packed row holds
+    uint4 *dst = reinterpret_cast<uint4 *>(st_desc);
+#pragma unroll 4
+    for (int e = threadIdx.x; e < rows * cpr; e += kBlock) {
+      const int r = i0 + (e >> lc), c = e & (cpr - 1);
+      const int valid = desc_bytes - 16 * c;          // descriptor bytes from this chunk on
+      const size_t at = (size_t)(base + st_left[base + r]) * raw_stride + 16 * c;
+      const size_t from = at + 16 <= raw_bytes ? at : raw_bytes - 16;
+      unsigned __int128 x;
+      __builtin_memcpy(&x, raw_left + from, 16);
+      const int back = (int)(at - from);
+      x >>= 8 * (back < 15 ? back : 15);
+      auto m = [&](int j) {
+        const int nb = valid - 4 * j;
+        return nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : (1u << (8 * nb)) - 1u);
+      };
+      dst[(size_t)(base + r) * cpr + c] = make_uint4((uint32_t)x & m(0), (uint32_t)(x >> 32) & m(1),
+                                                     (uint32_t)(x >> 64) & m(2), (uint32_t)(x >> 96) & m(3));
     }
   }
 }
