@@ -30,9 +30,12 @@ constexpr int kBlock = 256;
 // --------------------------------------------------------------------------
 // Stereo stage, first half: row/disparity filter + stable compaction (ballot
 // prefix) of the sorted matches.  One workgroup per frame walks them in chunks
-// of 256 so that the survivors keep their order.
+// of 1024 so that the survivors keep their order (a chunk is a chain of three
+// dependent loads: sixteen wavefronts have four times as many of them in flight
+// as four, and a frame of 1500 features is two chunks instead of six).
 // --------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
+constexpr int kCompactBlock = 1024;
+__global__ __launch_bounds__(kCompactBlock) void stereo_compact_kernel(
     const float *__restrict__ kp_left, const float *__restrict__ kp_right,
     const int32_t *__restrict__ off_left, const int32_t *__restrict__ off_right,
     const int32_t *__restrict__ idx2, const int32_t *__restrict__ dist2,
@@ -40,14 +43,14 @@ __global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
     int32_t *__restrict__ st_count, int32_t *__restrict__ st_left, int32_t *__restrict__ st_right,
     int32_t *__restrict__ st_dist, float *__restrict__ st_pix_left,
     float *__restrict__ st_pix_right) {
-  __shared__ int wave_tot[kBlock / 64];
+  __shared__ int wave_tot[kCompactBlock / 64];
   __shared__ int running;
   const int f = blockIdx.x;
   const int base = off_left[f], nq = off_left[f + 1] - base, rbase = off_right[f];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) running = 0;
   __syncthreads();
-  for (int chunk = 0; chunk < nq; chunk += kBlock) {
+  for (int chunk = 0; chunk < nq; chunk += kCompactBlock) {
     const int r = chunk + (int)threadIdx.x;
     bool keep = false;
     int q = 0, t = -1, d = -1;
@@ -70,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void stereo_compact_kernel(
     __syncthreads();
     int wave_base = 0, chunk_total = 0;
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
+    for (int w = 0; w < kCompactBlock / 64; ++w) {
       if (w < wave) wave_base += wave_tot[w];
       chunk_total += wave_tot[w];
     }
@@ -1008,7 +1011,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   if (rc) return rc;
   CamPair cam;
   for (int i = 0; i < 12; ++i) { cam.PL[i] = a->P_left[i]; cam.PR[i] = a->P_right[i]; }
-  hipLaunchKernelGGL(stereo_compact_kernel, dim3(F), dim3(kBlock), 0, st, a->d_kp_left,
+  hipLaunchKernelGGL(stereo_compact_kernel, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left,
                      a->d_kp_right, a->d_off_left, a->d_off_right, idx2, dist2, order,
                      a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
                      a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
