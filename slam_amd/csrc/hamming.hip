@@ -1023,14 +1023,13 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 // counting (many blocks per segment) for longer ones; knob 5 = 2 keeps the bitonic network.
 void launch_sort(const int32_t *d_dist, int dist_stride, int n_single, const int32_t *d_off,
                  const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order, hipStream_t st) {
-  // Measured: 500 segments of 1500 rows 30 us by the network (256 threads) against 60 by
-  // rank counting; 60 segments of 2000-8000 rows: the front-end pass 0.91 ms with the
-  // 1024-thread network against 1.03 ms with rank counting.
-  bool bitonic = max_n <= kBitonicMax;
+  // Measured: 500 segments of 1500 rows 16 us by the radix passes, 40 by the network, 60 by rank
+  // counting (700 rows: 9 / 20); two frames of 8000 features, the whole front-end call: 0.21 ms
+  // (radix) against 0.27 (network); 60 segments of 2000-8000 rows: the front-end pass 0.91 ms
+  // with the 1024-thread network against 1.03 ms with rank counting.  The radix kernel takes
+  // every segment that fits its LDS unless knob 5 says otherwise.
+  bool bitonic = max_n <= kBitonicMax;   // the segment fits one block's LDS (either LDS kernel)
   if (g_force_sort == 1) bitonic = false;
-  // 500 segments of 1500 rows: 40 us by the network, 16 by the radix passes (700 rows: 20 / 9);
-  // two frames of 8000 features, the whole front-end call: 0.27 / 0.21 ms.  The radix kernel
-  // takes every segment that fits its LDS unless knob 5 says otherwise.
   if (bitonic && g_force_sort != 2) {
     if (max_n <= 2048) {
       hipLaunchKernelGGL((radix_sort_kernel<256, 2048>), dim3(n_segments), dim3(256), 0, st, d_dist, dist_stride,
