@@ -1,5 +1,5 @@
 """One-off soak of the batched front-end for run-to-run determinism and agreement of its
-launch schemes: random sequences (2..40 frames, 60..2500 features per image, both
+launch schemes: random sequences (2..40 frames, every fourth 64..90; 60..2500 features per image, both
 cross-check flags, random iteration caps), each run twice and once more with each of the
 other RANSAC launch schemes forced (rounds; rounds with the merged tail) and once with the
 descriptor rows packed in front of the stereo matcher; every valid output row must be
@@ -42,7 +42,9 @@ def same(a, b):
 
 bad = 0
 for case in range(cases):
-    F = int(rng.integers(2, 41))
+    # every fourth case is long enough for the launch schemes of long calls (merged tail,
+    # blocks dealt to the XCDs by pair: 64 pairs or more)
+    F = int(rng.integers(2, 41)) if case % 4 else int(rng.integers(64, 91))
     lo = int(rng.integers(60, 1200))
     nfeat = (lo, lo + int(rng.integers(1, 1300)))
     seq = StereoSequence(cam, n_frames=F, n_features=nfeat, seed=int(rng.integers(1 << 30)), clutter=float(rng.uniform(0.2, 0.8)))
