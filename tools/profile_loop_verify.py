@@ -1,5 +1,6 @@
 """Runs the all-pairs keyframe verification once warm (for rocprofv3) and prints
-host-side timings of its parts."""
+host-side timings of its parts:  python tools/profile_loop_verify.py [keyframes] [matcher variant]
+(the variant is slamhip_tune knob 0; default: the library's choice)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -9,6 +10,9 @@ from slam_amd.backend.tracking.frontend import TrackingFrontend
 from slam_amd.utils.synth import StereoSequence
 
 KF = int(sys.argv[1]) if len(sys.argv) > 1 else 270
+if len(sys.argv) > 2:
+    from slam_amd import _lib
+    _lib.lib.slamhip_tune(0, int(sys.argv[2]))
 cam = CameraModel.kitti_like()
 seq = StereoSequence(cam, n_frames=KF * 17, n_features=1500, seed=7, clutter=0.6)
 frames = []
