@@ -90,6 +90,8 @@ void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t
                          const RawRows *raw = nullptr);
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,
               uint32_t *d_dst_b, int desc_bytes, int row_stride, hipStream_t st);
+// The sort algorithm forced through slamhip_tune(5, value): 0 = the library's choice.
+int sort_choice();
 int sort_by_distance(const int32_t *d_dist, int dist_stride, const int32_t *d_off,
                      const int32_t *d_cnt, int n_segments, int max_n, int32_t *d_order,
                      hipStream_t st);

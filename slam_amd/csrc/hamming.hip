@@ -19,6 +19,7 @@
 // distances, for the best and for the second best
 // (call site: frontend/vision/descriptor_matcher.py:33 of the reference).
 #include "common.h"
+#include "sort_device.h"
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
@@ -27,7 +28,7 @@
 
 namespace {
 
-constexpr int kKeyShift = 21;
+constexpr int kKeyShift = slamhip_dev::kSortKeyShift;   // one key layout for every sort kernel
 constexpr uint32_t kIdxMask = (1u << kKeyShift) - 1u;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
@@ -554,25 +555,15 @@ __global__ __launch_bounds__(T) void bitonic_sort_kernel(const int32_t *__restri
 }
 
 // ---------------------------------------------------------------------------
-// The same order by a stable least-significant-digit radix sort in LDS: the distance field of
-// the key has 11 bits, so two passes over 6-bit digits order the segment (equal distances stay
-// in index order, which is the order they start in).  A pass: every wavefront takes chunks of
-// 64 keys; the lanes of a chunk that hold the same digit find each other with one ballot per
-// digit bit, which gives a key's rank among them and their number -- noted per (digit, chunk);
-// an exclusive scan over those counts in (digit, chunk) order turns them into positions.  Ten
-// barriers per segment where the bitonic network has log2(N) (log2(N) + 1) / 2 + 2 = 68 for
-// 1500 keys, and work that grows with n, not n log^2 n.  One block per segment.
-// CAP = keys the block's LDS holds: 2 x CAP keys (ping-pong) + 64 x CAP / 64 16-bit counts.
+// The same order by a stable least-significant-digit radix sort in LDS (sort_device.h): one
+// block per segment, CAP = keys the block's LDS holds.
 // ---------------------------------------------------------------------------
 template <int T, int CAP>
 __global__ __launch_bounds__(T) void radix_sort_kernel(const int32_t *__restrict__ dist, int dist_stride,
                                                        int n_single, const int32_t *__restrict__ off,
                                                        const int32_t *__restrict__ cnt,
                                                        int32_t *__restrict__ order) {
-  constexpr int W = T / 64;
-  __shared__ uint32_t keys[2][CAP];
-  __shared__ uint16_t counts[CAP];        // [digit][chunk], chunks = ceil(n / 64) <= CAP / 64
-  __shared__ uint32_t wave_total[W];
+  __shared__ slamhip_dev::RadixSortLds<T, CAP> lds;
   const int seg = blockIdx.x;
   int s0 = 0, n = n_single;
   if (off != nullptr) {
@@ -580,70 +571,10 @@ __global__ __launch_bounds__(T) void radix_sort_kernel(const int32_t *__restrict
     n = cnt ? cnt[seg] : off[seg + 1] - s0;
   }
   if (n <= 0 || n > CAP) return;   // block-uniform; longer segments are not this kernel's (launch_sort)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int chunks = (n + 63) >> 6, entries = chunks << 6;
-  for (int i = threadIdx.x; i < n; i += T) {
-    const int d = dist[(size_t)(s0 + i) * dist_stride];
-    keys[0][i] = ((d < 0 ? 2047u : (uint32_t)d) << kKeyShift) | (uint32_t)i;
-  }
-  // digit of the key at position c * 64 + lane, its rank among the chunk's keys with that digit,
-  // and how many those are
-  auto classify = [&](const uint32_t *src, int c, int shift, uint32_t &key, int &digit, int &rank, int &same) {
-    const int e = (c << 6) + lane;
-    const bool valid = e < n;
-    key = valid ? src[e] : 0u;
-    digit = (int)((key >> shift) & 63u);
-    unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-      const bool bit = (digit >> b) & 1;
-      const unsigned long long has = __builtin_amdgcn_ballot_w64(bit);
-      peers &= bit ? has : ~has;
-    }
-    rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
-    same = __builtin_popcountll(peers);
-    return valid;
-  };
-  for (int pass = 0; pass < 2; ++pass) {
-    const uint32_t *src = keys[pass];
-    uint32_t *dst = keys[pass ^ 1];
-    const int shift = kKeyShift + 6 * pass;
-    for (int i = threadIdx.x; i < entries; i += T) counts[i] = 0;
-    __syncthreads();   // also: the keys of the previous step are all written
-    for (int c = wave; c < chunks; c += W) {
-      uint32_t key; int digit, rank, same;
-      if (classify(src, c, shift, key, digit, rank, same) && rank == 0)
-        counts[digit * chunks + c] = (uint16_t)same;
-    }
-    __syncthreads();
-    // exclusive scan of counts[0 .. entries): a run per thread, the runs' totals over the block
-    const int per = (entries + T - 1) / T;
-    const int b0 = min((int)threadIdx.x * per, entries), b1 = min(b0 + per, entries);
-    uint32_t mine = 0;
-    for (int i = b0; i < b1; ++i) mine += counts[i];
-    uint32_t incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t up = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += up;
-    }
-    if (lane == 63) wave_total[wave] = incl;
-    __syncthreads();
-    uint32_t running = incl - mine;
-    for (int w = 0; w < wave; ++w) running += wave_total[w];
-    for (int i = b0; i < b1; ++i) {
-      const uint32_t v = counts[i];
-      counts[i] = (uint16_t)running;
-      running += v;
-    }
-    __syncthreads();
-    for (int c = wave; c < chunks; c += W) {
-      uint32_t key; int digit, rank, same;
-      if (classify(src, c, shift, key, digit, rank, same)) dst[counts[digit * chunks + c] + rank] = key;
-    }
-    __syncthreads();
-  }
-  for (int r = threadIdx.x; r < n; r += T) order[s0 + r] = (int32_t)(keys[0][r] & kIdxMask);
+  for (int i = threadIdx.x; i < n; i += T)
+    lds.keys[0][i] = slamhip_dev::sort_key(dist[(size_t)(s0 + i) * dist_stride], i);
+  slamhip_dev::radix_sort_lds<T, CAP>(lds, n);
+  for (int r = threadIdx.x; r < n; r += T) order[s0 + r] = (int32_t)(lds.keys[0][r] & kIdxMask);
 }
 
 // ---------------------------------------------------------------------------
@@ -1277,6 +1208,8 @@ size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq,
 bool knn2_reads_raw(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt, int desc_bytes) {
   return make_plan(nq_total, nt_total, n_pairs, max_nq, max_nt, desc_bytes, 0, false).raw;
 }
+
+int sort_choice() { return g_force_sort; }
 
 int knn2_plan_splits(int n_pairs, int max_nq, int max_nt, int desc_bytes) {
   return make_plan(0, 0, n_pairs, max_nq, max_nt, desc_bytes, 0, true).splits;

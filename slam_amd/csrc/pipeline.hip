@@ -20,6 +20,7 @@
 #include "dlt_device.h"
 #include "p3p_device.h"
 #include "ransac_device.h"
+#include "sort_device.h"
 
 namespace {
 
@@ -35,6 +36,7 @@ constexpr int kBlock = 256;
 // as four, and a frame of 1500 features is two chunks instead of six).
 // --------------------------------------------------------------------------
 constexpr int kCompactBlock = 1024;
+constexpr int kFusedSortMax = 8192;   // matches of a frame / pair that one block's LDS sorts
 __global__ __launch_bounds__(kCompactBlock) void stereo_compact_kernel(
     const float *__restrict__ kp_left, const float *__restrict__ kp_right,
     const int32_t *__restrict__ off_left, const int32_t *__restrict__ off_right,
@@ -57,6 +59,77 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_compact_kernel(
     double uL = 0, vL = 0, uR = 0, vR = 0;
     if (r < nq) {
       q = order[base + r];
+      t = idx2[2 * (size_t)(base + q)];
+      d = dist2[2 * (size_t)(base + q)];
+      if (t >= 0) {
+        uL = (double)kp_left[2 * (size_t)(base + q)];
+        vL = (double)kp_left[2 * (size_t)(base + q) + 1];
+        uR = (double)kp_right[2 * (size_t)(rbase + t)];
+        vR = (double)kp_right[2 * (size_t)(rbase + t) + 1];
+        keep = stereo_keep(uL, vL, uR, vR, pix_thresh, disp_min);
+      }
+    }
+    const unsigned long long ballot = __ballot(keep);
+    const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(ballot);
+    __syncthreads();
+    int wave_base = 0, chunk_total = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactBlock / 64; ++w) {
+      if (w < wave) wave_base += wave_tot[w];
+      chunk_total += wave_tot[w];
+    }
+    const int pos = running + wave_base + prefix;
+    if (keep) {
+      const size_t o = (size_t)(base + pos);
+      st_left[o] = q;
+      st_right[o] = t;
+      st_dist[o] = d;
+      st_pix_left[2 * o + 0] = (float)uL;
+      st_pix_left[2 * o + 1] = (float)vL;
+      st_pix_right[2 * o + 0] = (float)uR;
+      st_pix_right[2 * o + 1] = (float)vR;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) running += chunk_total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) st_count[f] = running;
+}
+
+// The sort by distance and the compaction above in one launch, for frames whose matches fit one
+// block's LDS: the block sorts the frame's keys (sort_device.h) and walks them where they lie,
+// so the order never goes through memory and a launch is saved.  Same results as
+// sort_by_distance + stereo_compact_kernel.
+template <int CAP>
+__global__ __launch_bounds__(kCompactBlock) void stereo_sort_compact_kernel(
+    const float *__restrict__ kp_left, const float *__restrict__ kp_right,
+    const int32_t *__restrict__ off_left, const int32_t *__restrict__ off_right,
+    const int32_t *__restrict__ idx2, const int32_t *__restrict__ dist2, double pix_thresh,
+    double disp_min, int32_t *__restrict__ st_count, int32_t *__restrict__ st_left,
+    int32_t *__restrict__ st_right, int32_t *__restrict__ st_dist, float *__restrict__ st_pix_left,
+    float *__restrict__ st_pix_right) {
+  __shared__ RadixSortLds<kCompactBlock, CAP> lds;
+  __shared__ int wave_tot[kCompactBlock / 64];
+  __shared__ int running;
+  const int f = blockIdx.x;
+  const int base = off_left[f], nq = off_left[f + 1] - base, rbase = off_right[f];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) running = 0;
+  if (nq <= 0 || nq > CAP) {       // block-uniform (the host launches this kernel only when every frame fits)
+    if (threadIdx.x == 0) st_count[f] = 0;
+    return;
+  }
+  for (int i = threadIdx.x; i < nq; i += kCompactBlock)
+    lds.keys[0][i] = sort_key(dist2[2 * (size_t)(base + i)], i);
+  radix_sort_lds<kCompactBlock, CAP>(lds, nq);
+  for (int chunk = 0; chunk < nq; chunk += kCompactBlock) {
+    const int r = chunk + (int)threadIdx.x;
+    bool keep = false;
+    int q = 0, t = -1, d = -1;
+    double uL = 0, vL = 0, uR = 0, vR = 0;
+    if (r < nq) {
+      q = (int)(lds.keys[0][r] & kSortIdxMask);
       t = idx2[2 * (size_t)(base + q)];
       d = dist2[2 * (size_t)(base + q)];
       if (t >= 0) {
@@ -242,6 +315,56 @@ __global__ __launch_bounds__(kBlock) void temporal_gather_kernel(
   for (int c = 0; c < 2; ++c) {
     cpl[2 * o + c] = (float)pix_left[2 * (size_t)(tb + t) + c];
     cpr[2 * o + c] = (float)pix_right[2 * (size_t)(tb + t) + c];
+  }
+}
+
+// The sort by distance and the gather above in one launch, one block per pair, for pairs whose
+// matches fit one block's LDS (see stereo_sort_compact_kernel).  Same results as
+// sort_by_distance + temporal_gather_kernel.
+template <typename PIX, int T, int CAP>
+__global__ __launch_bounds__(T) void temporal_sort_gather_kernel(
+    const int32_t *__restrict__ qbase, const int32_t *__restrict__ qcnt,
+    const int32_t *__restrict__ tbase, const int32_t *__restrict__ tcnt,
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tidx2,
+    const int32_t *__restrict__ tdist2, const float *__restrict__ xyz,
+    const PIX *__restrict__ pix_left, const PIX *__restrict__ pix_right,
+    int32_t *__restrict__ tm_query, int32_t *__restrict__ tm_train, int32_t *__restrict__ tm_dist,
+    int32_t *__restrict__ tm_count, float *__restrict__ cx, float *__restrict__ cpl,
+    float *__restrict__ cpr) {
+  __shared__ RadixSortLds<T, CAP> lds;
+  const int p = blockIdx.x;
+  const int qb = qbase[p], tb = tbase[p], ob = obase[p];
+  const int nsort = qcnt[p];
+  const int n = tcnt[p] > 0 ? nsort : 0;  // no train rows -> no matches
+  if (n <= 0 || n > CAP) {                // block-uniform
+    if (threadIdx.x == 0) tm_count[p] = 0;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += T) lds.keys[0][i] = sort_key(tdist2[2 * (size_t)(ob + i)], i);
+  radix_sort_lds<T, CAP>(lds, n);
+  for (int r = threadIdx.x; r < n; r += T) {
+    const int q = (int)(lds.keys[0][r] & kSortIdxMask);
+    const int t = tidx2[2 * (size_t)(ob + q)];
+    // query rows without a match (cross-check) sort last: the matches are a prefix of
+    // the sorted rows, and the row that ends it writes the count
+    const bool next_matched =
+        r + 1 < n && tidx2[2 * (size_t)(ob + (int)(lds.keys[0][r + 1] & kSortIdxMask))] >= 0;
+    if (t < 0) {
+      if (r == 0) tm_count[p] = 0;
+      continue;
+    }
+    if (!next_matched) tm_count[p] = r + 1;
+    const size_t o = (size_t)(ob + r);
+    tm_query[o] = q;
+    tm_train[o] = t;
+    tm_dist[o] = tdist2[2 * (size_t)(ob + q)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cx[3 * o + c] = xyz[3 * (size_t)(qb + q) + c];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cpl[2 * o + c] = (float)pix_left[2 * (size_t)(tb + t) + c];
+      cpr[2 * o + c] = (float)pix_right[2 * (size_t)(tb + t) + c];
+    }
   }
 }
 
@@ -1007,14 +1130,24 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                        dim3(kBlock), 0, st, bid, a->n_left_total, idx2, dist2);
     SLAMHIP_CHECK_LAUNCH();
   }
-  rc = slamhip_internal::sort_by_distance(dist2, 2, a->d_off_left, nullptr, F, a->max_left, order, st);
-  if (rc) return rc;
+  // sort by distance + filter + compaction: one launch where a frame's matches fit a block's LDS
+  // (and no sort algorithm is forced), else the sort's launch and the compaction's
+  const bool fused_sort = slamhip_internal::sort_choice() == 0 && a->max_left <= kFusedSortMax;
   CamPair cam;
   for (int i = 0; i < 12; ++i) { cam.PL[i] = a->P_left[i]; cam.PR[i] = a->P_right[i]; }
-  hipLaunchKernelGGL(stereo_compact_kernel, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left,
-                     a->d_kp_right, a->d_off_left, a->d_off_right, idx2, dist2, order,
-                     a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
-                     a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
+  if (fused_sort) {
+    auto k = a->max_left <= 2048 ? stereo_sort_compact_kernel<2048> : stereo_sort_compact_kernel<kFusedSortMax>;
+    hipLaunchKernelGGL(k, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, a->d_off_left,
+                       a->d_off_right, idx2, dist2, a->pixel_thresh, a->disparity_min, a->d_st_count,
+                       a->d_st_left, a->d_st_right, a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
+  } else {
+    rc = slamhip_internal::sort_by_distance(dist2, 2, a->d_off_left, nullptr, F, a->max_left, order, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(stereo_compact_kernel, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left,
+                       a->d_kp_right, a->d_off_left, a->d_off_right, idx2, dist2, order,
+                       a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
+                       a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
+  }
   hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F), dim3(kBlock),
                      0, st, a->d_off_left, a->d_st_count, a->d_st_left, a->d_st_pix_left,
                      a->d_st_pix_right, packL, W, L.raw ? a->d_des_left : nullptr, a->desc_stride,
@@ -1048,14 +1181,24 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                        dim3(kBlock), 0, st, bid, a->n_left_total, tidx2, tdist2);
     SLAMHIP_CHECK_LAUNCH();
   }
-  rc = slamhip_internal::sort_by_distance(tdist2, 2, a->d_off_left, a->d_st_count, F - 1, a->max_left,
-                                          order2, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(temporal_gather_kernel<float>,
-                     dim3(slamhip_ceil_div(a->max_left, kBlock), F - 1), dim3(kBlock), 0, st,
-                     a->d_off_left, a->d_st_count, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left,
-                     tidx2, tdist2, order2, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right,
-                     a->d_tm_query, a->d_tm_train, a->d_tm_dist, tcount, cx, cpl, cpr);
+  if (fused_sort) {
+    // many short pairs: 256 threads a block; few long ones: 1024
+    auto k = a->max_left <= 2048 ? temporal_sort_gather_kernel<float, 256, 2048>
+                                 : temporal_sort_gather_kernel<float, 1024, kFusedSortMax>;
+    hipLaunchKernelGGL(k, dim3(F - 1), dim3(a->max_left <= 2048 ? 256 : 1024), 0, st, a->d_off_left,
+                       a->d_st_count, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left, tidx2, tdist2,
+                       a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_tm_query, a->d_tm_train,
+                       a->d_tm_dist, tcount, cx, cpl, cpr);
+  } else {
+    rc = slamhip_internal::sort_by_distance(tdist2, 2, a->d_off_left, a->d_st_count, F - 1, a->max_left,
+                                            order2, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(temporal_gather_kernel<float>,
+                       dim3(slamhip_ceil_div(a->max_left, kBlock), F - 1), dim3(kBlock), 0, st,
+                       a->d_off_left, a->d_st_count, a->d_off_left + 1, a->d_st_count + 1, a->d_off_left,
+                       tidx2, tdist2, order2, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right,
+                       a->d_tm_query, a->d_tm_train, a->d_tm_dist, tcount, cx, cpl, cpr);
+  }
   SLAMHIP_CHECK_LAUNCH();
 
   RansacParams prm;

@@ -1,0 +1,100 @@
+// Device code shared by the kernels that order a segment of matches by (distance, index): a
+// stable least-significant-digit radix sort of one segment in one block's LDS.
+//
+// Keys are dist << 21 | index (absent distances, < 0, take 2047 and sort last); the distance
+// field has 11 bits, so two passes over 6-bit digits order the segment, and equal distances stay
+// in index order, which is the order they start in.  A pass: every wavefront takes chunks of 64
+// keys; the lanes of a chunk that hold the same digit find each other with one ballot per digit
+// bit, which gives a key's rank among them and their number -- noted per (digit, chunk); an
+// exclusive scan over those counts in (digit, chunk) order turns them into positions.  Ten
+// barriers per segment where a bitonic network has log2(N) (log2(N) + 1) / 2 + 2 = 68 for 1500
+// keys, and work that grows with n, not n log^2 n.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace slamhip_dev {
+
+constexpr int kSortKeyShift = 21;
+constexpr uint32_t kSortIdxMask = (1u << kSortKeyShift) - 1u;
+
+__device__ __forceinline__ uint32_t sort_key(int dist, int index) {
+  return ((dist < 0 ? 2047u : (uint32_t)dist) << kSortKeyShift) | (uint32_t)index;
+}
+
+// LDS of a block of T threads that sorts up to CAP keys: 2 x CAP keys (ping-pong) + CAP 16-bit
+// counts ([digit][chunk], chunks = ceil(n / 64) <= CAP / 64) + the wavefronts' totals.
+template <int T, int CAP>
+struct RadixSortLds {
+  uint32_t keys[2][CAP];
+  uint16_t counts[CAP];
+  uint32_t wave_total[T / 64];
+};
+
+// Sorts s.keys[0][0 .. n) (written by the block; n <= CAP, block-uniform) in place; every
+// thread of the block calls it; the result is visible to all of them when it returns.
+template <int T, int CAP>
+__device__ __forceinline__ void radix_sort_lds(RadixSortLds<T, CAP> &s, int n) {
+  constexpr int W = T / 64;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunks = (n + 63) >> 6, entries = chunks << 6;
+  // digit of the key at position c * 64 + lane, its rank among the chunk's keys with that digit,
+  // and how many those are
+  auto classify = [&](const uint32_t *src, int c, int shift, uint32_t &key, int &digit, int &rank, int &same) {
+    const int e = (c << 6) + lane;
+    const bool valid = e < n;
+    key = valid ? src[e] : 0u;
+    digit = (int)((key >> shift) & 63u);
+    unsigned long long peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+      const bool bit = (digit >> b) & 1;
+      const unsigned long long has = __builtin_amdgcn_ballot_w64(bit);
+      peers &= bit ? has : ~has;
+    }
+    rank = __builtin_popcountll(peers & ((1ull << lane) - 1ull));
+    same = __builtin_popcountll(peers);
+    return valid;
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint32_t *src = s.keys[pass];
+    uint32_t *dst = s.keys[pass ^ 1];
+    const int shift = kSortKeyShift + 6 * pass;
+    for (int i = threadIdx.x; i < entries; i += T) s.counts[i] = 0;
+    __syncthreads();   // also: the keys of the previous step are all written
+    for (int c = wave; c < chunks; c += W) {
+      uint32_t key; int digit, rank, same;
+      if (classify(src, c, shift, key, digit, rank, same) && rank == 0)
+        s.counts[digit * chunks + c] = (uint16_t)same;
+    }
+    __syncthreads();
+    // exclusive scan of counts[0 .. entries): a run per thread, the runs' totals over the block
+    const int per = (entries + T - 1) / T;
+    const int b0 = min((int)threadIdx.x * per, entries), b1 = min(b0 + per, entries);
+    uint32_t mine = 0;
+    for (int i = b0; i < b1; ++i) mine += s.counts[i];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) s.wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t running = incl - mine;
+    for (int w = 0; w < wave; ++w) running += s.wave_total[w];
+    for (int i = b0; i < b1; ++i) {
+      const uint32_t v = s.counts[i];
+      s.counts[i] = (uint16_t)running;
+      running += v;
+    }
+    __syncthreads();
+    for (int c = wave; c < chunks; c += W) {
+      uint32_t key; int digit, rank, same;
+      if (classify(src, c, shift, key, digit, rank, same)) dst[s.counts[digit * chunks + c] + rank] = key;
+    }
+    __syncthreads();
+  }
+}
+
+}  // namespace slamhip_dev

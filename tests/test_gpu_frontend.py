@@ -629,3 +629,36 @@ def test_frontend_reads_descriptor_rows_in_place(nbytes, cross):
         o, m = int(inp.off_left[f]), int(ha["st_count"][f])
         np.testing.assert_array_equal(da[o:o + m], db[o:o + m])
         assert not da[o:o + m].view(np.uint8)[:, nbytes:].any()
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_fused_sort_launches_equal_the_separate_ones(cross):
+    """Where a frame's matches fit a block's LDS the front-end sorts and compacts (stereo) or
+    sorts and gathers (temporal) in one launch; forcing a sort algorithm (tune knob 5) takes
+    the separate sort launch instead.  Every output must agree, for ragged frames, with and
+    without cross-check (unmatched rows sort last and end the gather)."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    F = 6
+    seq = StereoSequence(cam, n_frames=F, n_features=(100, 2600), seed=17 + cross, clutter=0.6)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(F))]
+    frames[2] = tuple(a[:3] for a in frames[2])        # a frame of three features
+    fe = TrackingFrontend(cam, n_iter_max=300, seed=5, stereo_cross_check=cross, frame_cross_check=cross)
+    inp = fe.upload(frames)
+    got = []
+    try:
+        for algo in (0, 2, 1):
+            _lib.lib.slamhip_tune(5, algo)
+            res = fe.run(inp)
+            rows = [res.frame(f) for f in range(F)] + [res.pair(p) for p in range(F - 1)]
+            got.append([{k: np.array(v, copy=True) for k, v in r.items() if isinstance(v, np.ndarray)} for r in rows])
+    finally:
+        _lib.lib.slamhip_tune(5, 0)
+    assert sum(len(r["xyz"]) for r in got[0][:F]) > 500
+    for other in got[1:]:
+        for x, y in zip(got[0], other):
+            assert x.keys() == y.keys()
+            for k in x:
+                np.testing.assert_array_equal(x[k], y[k], err_msg=k)
