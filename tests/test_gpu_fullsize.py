@@ -191,3 +191,47 @@ def test_all_pairs_of_270_keyframes():
             assert all(min(abs(eL[k] - 1.5), abs(eR[k] - 1.5)) < 1e-6 for k in bad)
             # other random samples on ~60-80 supporters 14 m apart: the same motion, not the same digits
             assert np.abs(first["Rt"][p] - ref["Rt"]).max() < 0.5
+
+
+def test_2761_frames_cut_into_eight_shards_equal_the_uncut_run():
+    """A KITTI-05-sized sequence (2761 stereo frames x 1500 features) as eight ranks would
+    process it: every rank's frame range (with its halo frame) through the front-end and the
+    device-side record packing, one after the other on this GPU, the eight records merged as
+    rank 0 merges what the gather delivers -- against the same sequence in one piece.  The
+    device sampler is keyed by the pair's index in the sequence, so the two are equal bit for bit."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking import sharding
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam = CameraModel.kitti_like()
+    F, world = 2761, 8
+    seq, frames = _frames(cam, F, 1500, seed=31)
+    fe = TrackingFrontend(cam, n_iter_max=2500, seed=17)
+    whole = sharding.run_sharded(fe, frames, 0, 1)
+    blobs, covered = [], 0
+    for rank in range(world):
+        lo, hi, (plo, phi), (flo, fhi) = sharding.frames_for_rank(F, world, rank)
+        assert hi - lo <= (F + world - 1) // world + 1             # a share of the sequence plus one halo frame
+        covered += phi - plo
+        res = fe.run(list(frames[lo:hi]), first_pair=plo)
+        blobs.append(sharding.pack_result(res, (flo - lo, fhi - lo), (plo - lo, phi - lo), flo, plo).cpu().numpy())
+        del res
+    assert covered == F - 1
+    merged = sharding.merge_records(blobs, F)
+    assert sum(b.nbytes for b in blobs) < 400e6                    # what the gather moves: ~70 KB per frame
+    np.testing.assert_array_equal(merged.relative_Rts, whole.relative_Rts)
+    assert merged.relative_Rts.shape == (F - 1, 3, 4)
+    for f in range(0, F, 13):
+        a, b = merged.frame(f), whole.frame(f)
+        assert a.keys() == b.keys()
+        for k in b:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"frame {f} {k}")
+    for p in list(range(0, F - 1, 11)) + [F - 2]:
+        a, b = merged.pair(p), whole.pair(p)
+        for k in ("query_idx", "train_idx", "dist", "mask", "Rt", "Rt_ransac"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"pair {p} {k}")
+        assert a["best_index"] == b["best_index"] and a["iterations"] == b["iterations"]
+    # every pair near the truth, and the poses right around each cut
+    rel = merged.relative_Rts
+    _assert_rigid(rel)
+    err = np.abs(rel[:, :, 3] - np.stack([seq.relative_pose(p + 1)[:, 3] for p in range(F - 1)])).max()
+    assert err < 0.05, err
