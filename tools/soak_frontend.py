@@ -4,7 +4,7 @@ cross-check flags, random iteration caps), each run twice and once more with eac
 other RANSAC launch schemes forced (rounds; rounds with the merged tail) and once with the
 descriptor rows packed in front of the stereo matcher and once with the sorts as launches of
 their own; every valid output row must be identical bit for bit.
-python tools/soak_frontend.py [cases]"""
+python tools/soak_frontend.py [cases [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -13,7 +13,7 @@ from slam_amd.backend.tracking.frontend import TrackingFrontend
 from slam_amd.utils.synth import StereoSequence
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(99)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 99)
 cam = CameraModel.kitti_like()
 
 

@@ -9,7 +9,7 @@ from slam_amd import _lib, kernels
 from oracle import slam_oracle as so
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-rng = np.random.default_rng(777)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 777)
 bad = 0
 for case in range(cases):
     d = int(rng.integers(1, 129))

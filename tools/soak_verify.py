@@ -10,7 +10,7 @@ from slam_amd.backend.tracking.frontend import TrackingFrontend
 from slam_amd.utils.synth import StereoSequence
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = np.random.default_rng(5)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 cam = CameraModel.kitti_like()
 bad = 0
 for case in range(cases):
