@@ -55,8 +55,11 @@ const char *slamhip_strerror(int code);
 /* Diagnostics only (kernel-variant benchmarks): knob 0 = matcher kernel variant
  * (-1 auto; 0..5 popcount kernels; 8 matrix-core kernel, 9 / 10 the same with
  * 1 / 2 groups of 32 queries per wave), knob 1 = forced number of train splits (0 auto), knob 2 = packed-fp32
- * screening in the consensus counting kernels (1 = on, the default; 0 = fp64 only;
- * the counts are identical either way), knob 3 = matcher block size (0 auto, 256 or
+ * screening in the consensus counting kernels (1 = on, the default: pair verification, whose
+ * pairs are mostly unrelated, dismisses most hypothesis-point combinations by the left image
+ * alone and counts each hypothesis' own sample points where it is solved; 2 = on, every
+ * combination screened everywhere; 3 = the pair-verification scheme everywhere; 0 = fp64 only;
+ * the counts are identical in all four), knob 3 = matcher block size (0 auto, 256 or
  * 128 queries per block), knob 4 = pair RANSAC launch scheme (0 auto: calls with at
  * most 64 pairs solve and count every hypothesis in one pass, longer front-end calls run
  * three rounds of 256 hypotheses and the rest of the cap as one merged launch; 1 always

@@ -35,7 +35,9 @@ static inline int slamhip_packed_words(int desc_bytes) {
 // Cross-translation-unit entry points (not part of the C ABI).
 namespace slamhip_internal {
 // 1: consensus counting screens in packed fp32 and re-evaluates undecided points in
-// fp64 (same counts); 0: fp64 only.  Set through slamhip_tune(2, value).
+// fp64 (same counts), with the sparse scheme (count_chunk_inliers_sparse) where the caller
+// says its pairs are mostly unrelated; 2 / 3: the same with that scheme never / always;
+// 0: fp64 only.  Set through slamhip_tune(2, value).
 extern int g_ransac_screen;
 // Pair RANSAC launch scheme: 0 = chosen from the number of pairs (single pass for few
 // pairs; three rounds and a merged tail for the front-end's long calls), 1 = always rounds

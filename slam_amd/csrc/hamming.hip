@@ -1002,7 +1002,7 @@ extern "C" {
 int slamhip_tune(int knob, int value) {
   if (knob == 0) g_force_variant = value;
   else if (knob == 1) g_force_splits = value;
-  else if (knob == 2) slamhip_internal::g_ransac_screen = value ? 1 : 0;
+  else if (knob == 2) slamhip_internal::g_ransac_screen = (value >= 0 && value <= 3) ? value : 1;
   else if (knob == 3) g_force_threads = value;
   else if (knob == 4) slamhip_internal::g_ransac_mode = value;
   else if (knob == 5) g_force_sort = value;

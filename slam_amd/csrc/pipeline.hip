@@ -501,14 +501,20 @@ struct RansacParams {
 // generated hypotheses for; a launch with `generate` off clears the count instead.
 // `hyp32` (may be null): per valid hypothesis the fp32 image of its projection matrices and
 // its error-bound constants (Hyp32), hyp32[(row * kHyp32Floats + field) * kHypPerRound + lane].
-constexpr int kHyp32Floats = 32;   // 29 used: PL[12], PR[12], A3xy, Atxy, A3w, Atw, cR
+// `cpr_own` (may be null; needs hyp32): the right-image pixels; the launch then counts, per
+// hypothesis, the inliers among the staged pairs (points 2r, 2r + 1) that hold its own sample
+// points and starts the hypothesis' count there instead of at zero: the counting launch for
+// mostly unrelated pairs leaves exactly those pairs out (count_chunk_inliers_sparse).
+constexpr int kHyp32Floats = 32;   // 31 used: PL[12], PR[12], A3xy, Atxy, A3w, Atw, cR, and the four sample
+                                   // indices, 16 bits each, in two more (kSampleIndexMax)
+constexpr int kSampleIndexMax = 65535;
 __global__ __launch_bounds__(kBlock)
 __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void ransac_solve_kernel(
     int first_block, int slots, int replay, int generate, const int32_t *__restrict__ obase,
     const int32_t *__restrict__ tm_count, const float *__restrict__ cx, const float *__restrict__ cpl,
     const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
     int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info,
-    int32_t *__restrict__ list, float *__restrict__ hyp32) {
+    int32_t *__restrict__ list, float *__restrict__ hyp32, const float *__restrict__ cpr_own) {
   __shared__ int sh[3];  // stopped, winner lane of the replayed round, iterations required
   __shared__ int red[4 + kBlock / 64];
   const int p = blockIdx.x, slot = blockIdx.y;
@@ -556,6 +562,7 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
   if (list != nullptr && threadIdx.x == 0 && active)      // lane 0 holds the block's first hypothesis
     list[1 + atomicAdd(&list[0], 1)] = (int32_t)row;
   bool valid = false;
+  int own = 0;   // inliers among the staged pairs of the hypothesis' own sample points (cpr_own)
   if (active) {
     const float *X = cx + 3 * (size_t)obase[p];
     const float *mL = cpl + 2 * (size_t)obase[p];
@@ -604,10 +611,37 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
         for (int i = 0; i < 12; ++i) { o[i * kHypPerRound] = h.PL[i]; o[(12 + i) * kHypPerRound] = h.PR[i]; }
         o[24 * kHypPerRound] = h.A3xy; o[25 * kHypPerRound] = h.Atxy; o[26 * kHypPerRound] = h.A3w;
         o[27 * kHypPerRound] = h.Atw;  o[28 * kHypPerRound] = h.cR;
+        o[29 * kHypPerRound] = __int_as_float((s4[0] & 0xFFFF) | (s4[1] << 16));
+        o[30 * kHypPerRound] = __int_as_float((s4[2] & 0xFFFF) | (s4[3] << 16));
+        if (cpr_own != nullptr) {
+          const float *mR = cpr_own + 2 * (size_t)obase[p];
+          const double thr2 = threshold_squared(prm.thresh);
+          // straight-line: the eight points' loads go out together (indices clamped, results
+          // of pairs seen before or past the end dropped)
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int r = (s4[k] & 0xFFFF) >> 1;   // as the counting launch reads it back
+            bool fresh = true;
+#pragma unroll
+            for (int j = 0; j < k; ++j) fresh = fresh && ((s4[j] & 0xFFFF) >> 1) != r;
+#pragma unroll
+            for (int pt = 0; pt < 2; ++pt) {
+              const size_t g = (size_t)min(2 * r + pt, n - 1);
+              // the staged form of the point (stage_pair), so that the decision is
+              // inlier_exact_staged's, as for any point the screen leaves undecided
+              float f[13];
+              f[0] = X[3 * g]; f[2] = X[3 * g + 1]; f[4] = X[3 * g + 2];
+              f[6] = mL[2 * g]; f[8] = mL[2 * g + 1];
+              f[10] = mR[2 * g]; f[12] = mR[2 * g + 1];
+              const bool in = inlier_exact_staged<true>(f, PL, PR, prm.thresh, thr2);
+              own += (fresh && 2 * r + pt < n && in) ? 1 : 0;
+            }
+          }
+        }
       }
     }
   }
-  counts[row * kHypPerRound + threadIdx.x] = active ? (valid ? 0 : -1) : -2;
+  counts[row * kHypPerRound + threadIdx.x] = active ? (valid ? own : -1) : -2;
 }
 
 // grid (point spans, slots * kHypPerRound / 64, pairs), one wavefront per block; a span is
@@ -616,7 +650,8 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
 // rounds, which few pairs reach, use one block per 64 hypotheses so that a launch
 // with nothing left to do costs a few thousand empty blocks instead of tens of
 // thousands.
-// MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair.
+// MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair, 3 = as 2 for pairs
+// that are mostly unrelated (count_chunk_inliers_sparse; needs the solve launch's hyp32 table).
 constexpr int kWideRounds = 3;
 // One wavefront's share: hypotheses [64 * hyp_group, +64) of table row `row` (a block of
 // pair p's hypotheses) against the pair's correspondences [span0, span0 + span_len).
@@ -649,6 +684,7 @@ __device__ __forceinline__ void ransac_count_item(
   };
   double PL[12], PR[12];
   Hyp32 h32;
+  int s4[4] = {0, 0, 0, 0};   // MODE 3: the hypothesis' sample points (indices within the pair)
   if (!screened) {
     projections(PL, PR);
   } else if (hyp32 != nullptr) {
@@ -657,6 +693,11 @@ __device__ __forceinline__ void ransac_count_item(
     for (int i = 0; i < 12; ++i) {
       h32.PL[i] = valid ? o[i * kHypPerRound] : 0.0f;
       h32.PR[i] = (MODE == 1 && valid) ? o[(12 + i) * kHypPerRound] : 0.0f;
+    }
+    if (MODE == 3) {
+      const unsigned s01 = valid ? __float_as_uint(o[29 * kHypPerRound]) : 0u;
+      const unsigned s23 = valid ? __float_as_uint(o[30 * kHypPerRound]) : 0u;
+      s4[0] = (int)(s01 & 0xFFFFu); s4[1] = (int)(s01 >> 16); s4[2] = (int)(s23 & 0xFFFFu); s4[3] = (int)(s23 >> 16);
     }
     h32.A3xy = valid ? o[24 * kHypPerRound] : 0.0f; h32.Atxy = valid ? o[25 * kHypPerRound] : 0.0f;
     h32.A3w = valid ? o[26 * kHypPerRound] : 0.0f;  h32.Atw = valid ? o[27 * kHypPerRound] : 0.0f;
@@ -693,12 +734,21 @@ __device__ __forceinline__ void ransac_count_item(
     }
     __syncthreads();
     if (valid) {
-      if (screened)
-        c += count_chunk_inliers_screened<MODE == 2>(ldsf, cnt, h32, sc, thr2, [&](const float *f) {
-          double PL_[12], PR_[12];
-          projections(PL_, PR_);
-          return inlier_exact_staged<MODE == 2>(f, PL_, PR_, thresh, thr2);
-        });
+      auto exact = [&](const float *f) {
+        double PL_[12], PR_[12];
+        projections(PL_, PR_);
+        return inlier_exact_staged<MODE >= 2>(f, PL_, PR_, thresh, thr2);
+      };
+      if (MODE == 3) {
+        unsigned long long mine = 0ull;   // staged pairs of this chunk that hold one of the lane's sample points
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int d = s4[k] - p0;
+          if (d >= 0 && d < cnt) mine |= 1ull << (d >> 1);
+        }
+        c += count_chunk_inliers_sparse<true>(ldsf, cnt, h32, sc, thr2, mine, exact);
+      } else if (screened)
+        c += count_chunk_inliers_screened<MODE >= 2>(ldsf, cnt, h32, sc, thr2, exact);
       else
         c += count_chunk_inliers(lds, cnt, PL, PR, thresh, thr2);
     }
@@ -774,6 +824,10 @@ __global__ __launch_bounds__(64) void ransac_count_screened_kernel(SLAMHIP_COUNT
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void ransac_count_rectified_kernel(SLAMHIP_COUNT_ARGS) {
   ransac_count_body<2>(SLAMHIP_COUNT_PASS);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ransac_count_rectified_sparse_kernel(SLAMHIP_COUNT_ARGS) {
+  ransac_count_body<3>(SLAMHIP_COUNT_PASS);
 }
 __global__ __launch_bounds__(64) void ransac_count_list_fp64_kernel(SLAMHIP_COUNT_ARGS, const int32_t *__restrict__ list) {
   ransac_count_list_body<0>(SLAMHIP_COUNT_PASS, list);
@@ -912,7 +966,7 @@ size_t ransac_workspace_bytes(int n_pairs, int n_iter_max, bool merge_tail = fal
 int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *cx, const float *cpl,
                     const float *cpr, const int32_t *samples, RansacParams prm, int n_pairs,
                     int max_points, double *pose_ransac, uint8_t *tm_mask, int32_t *info, void *ws,
-                    hipStream_t st, bool merge_tail = false) {
+                    hipStream_t st, bool merge_tail = false, bool mostly_unrelated = false) {
   if (n_pairs <= 0) return SLAMHIP_OK;
   const int group = n_pairs < kPairGroup ? n_pairs : kPairGroup;
   const int slots = single_pass_slots(n_pairs, prm.n_iter_max);
@@ -933,12 +987,18 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
   for (int g0 = 0; g0 < n_pairs; g0 += group) {
     const int np = n_pairs - g0 < group ? n_pairs - g0 : group;
     prm.pair0 = pair0 + g0;
-    auto count = mode == 2 ? ransac_count_rectified_kernel
+    // tune knob 2: 1 = the sparse count where the caller expects mostly unrelated pairs,
+    // 2 = never, 3 = always
+    const int scr = slamhip_internal::g_ransac_screen;
+    const bool sparse = mode == 2 && max_points <= kSampleIndexMax && (scr == 3 || (scr == 1 && mostly_unrelated));
+    auto count = sparse ? ransac_count_rectified_sparse_kernel
+                 : mode == 2 ? ransac_count_rectified_kernel
                  : mode == 1 ? ransac_count_screened_kernel : ransac_count_fp64_kernel;
     for (int r = 0; r < rounds; ++r) {
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, slots), dim3(kBlock), 0, st, r, slots, r > 0 ? 1 : 0, 1,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr, hyp32);
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, (int32_t *)nullptr, hyp32,
+                         sparse ? cpr : (const float *)nullptr);
       // narrow only where that still leaves at least a thousand wavefronts of work
       const int per_span = (r < kWideRounds || np * (kHypPerRound / 64) < 1024) ? 1 : chunks;
       // a pair's blocks on one XCD where there are pairs enough to load the eight evenly (measured:
@@ -954,10 +1014,12 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       // replay of the last wide round (state and winner pose up to date), then every block left
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, 1), dim3(kBlock), 0, st, kWideRounds, 1, 1, 0,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr);
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr,
+                         (const float *)nullptr);
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, tail), dim3(kBlock), 0, st, kWideRounds, tail, 0, 1,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt_tail, counts_tail,
-                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr);
+                         pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr,
+                         (const float *)nullptr);
       auto count_list = mode == 2 ? ransac_count_list_rectified_kernel
                         : mode == 1 ? ransac_count_list_screened_kernel : ransac_count_list_fp64_kernel;
       const long long most = (long long)np * tail * (kHypPerRound / 64) * chunks;
@@ -1380,7 +1442,8 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
     prm.seq0 = c0;
     rc = run_pair_ransac(ob, tcount + c0, cx, cpl, cpr, nullptr, prm, np, a->max_q,
                          a->d_pose_ransac + 12 * (size_t)c0, a->d_tm_mask,
-                         a->d_info + 8 * (size_t)c0, ransac_ws, st);
+                         a->d_info + 8 * (size_t)c0, ransac_ws, st, /*merge_tail=*/false,
+                         /*mostly_unrelated=*/true);
     if (rc) return rc;
     rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, ob, tcount + c0, np, a->K,
                                        a->d_pose_ransac + 12 * (size_t)c0, a->refine_iters,
@@ -1392,3 +1455,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
 }
 
 }  // extern "C"
+
+#ifdef SLAMHIP_DEBUG_SPARSE
+extern "C" int slamhip_debug_counters(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(slamhip_dev::g_dbg), 16); }
+#endif

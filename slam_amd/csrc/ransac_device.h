@@ -159,6 +159,9 @@ __device__ __forceinline__ int count_chunk_inliers(const double *__restrict__ ld
 // M_right (rectified_stereo()).  The fp64 path uses the real last column of P_right.
 // ---------------------------------------------------------------------------
 typedef float f2 __attribute__((ext_vector_type(2)));
+#ifdef SLAMHIP_DEBUG_SPARSE
+static __device__ unsigned long long g_dbg[2];
+#endif
 
 constexpr int kPairStride = 16;  // floats per staged pair: X Y Z uL vL uR vR s^2 (s = |X|+|Y|+|Z|), two lanes each
 constexpr float kEps32 = 5.9604645e-8f;
@@ -334,6 +337,35 @@ __device__ __forceinline__ void screen_pair(const float *__restrict__ rec, const
   }
 }
 
+// The left camera alone (rectified pair): the lanes (of those active) for which this cannot put
+// both points of the staged pair outside for sure.  dL and T are those of screen_pair, whose
+// verdict "outside for sure" is max(dL, dR) > T: dL > T implies it.  For a lane not in the
+// result screen_pair counts nothing and leaves nothing undecided.  19 instructions against 33.
+__device__ __forceinline__ unsigned long long left_open(const float *__restrict__ rec, const Hyp32 &h,
+                                                        f2 nthr2f, f2 aT, f2 ca, f2 cb) {
+  const f2 *q = reinterpret_cast<const f2 *>(rec);
+  const f2 X = q[0], Y = q[1], Z = q[2];
+  const f2 C = fma2(q[7], ca, cb);
+  const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
+  const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
+  const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
+  const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
+  const f2 w2 = w * w;
+  const f2 dL = fma2(nthr2f, w2, fma2(dx, dx, dy * dy));   // exactly screen_pair's
+  const f2 TL = fma2(aT, w2, C);
+  const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+  // a NaN on either side (anything outside the screen's domain) compares false: stays open
+  return active & ~(__builtin_amdgcn_ballot_w64(dL.x > TL.x) & __builtin_amdgcn_ballot_w64(dL.y > TL.y));
+}
+
+// 1 when the lane mask is not empty, in a scalar register (written as a select the compiler
+// takes the flag through a vector register and keeps everything derived from it there).
+__device__ __forceinline__ unsigned any_lane(unsigned long long lanes) {
+  unsigned r;
+  asm("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(r) : "s"(lanes) : "scc");
+  return r;
+}
+
 // fp64 decision for the staged point at f (lane k of its pair: f = record + k).
 template <bool RECT>
 __device__ __forceinline__ bool inlier_exact_staged(const float *__restrict__ f, const double (&PL)[12],
@@ -381,9 +413,7 @@ __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restr
     screen_pair<RECT>(lds + j * kPairStride, h, nthr2f, aT, ca, cb, a_in0, a_in1, a_open0, a_open1);
     screen_pair<RECT>(lds + (j + 1) * kPairStride, h, nthr2f, aT, ca, cb, b_in0, b_in1, b_open0, b_open1);
     c += (a_in0 ? 1 : 0) + (a_in1 ? 1 : 0) + (b_in0 ? 1 : 0) + (b_in1 ? 1 : 0);
-    // population counts of lane masks: scalar instructions
-    const unsigned na = __builtin_popcountll(a_open0 | a_open1), nb = __builtin_popcountll(b_open0 | b_open1);
-    noted |= ((unsigned long long)(na < 1u ? na : 1u) | ((unsigned long long)(nb < 1u ? nb : 1u) << 1)) << j;
+    noted |= ((unsigned long long)any_lane(a_open0 | a_open1) | ((unsigned long long)any_lane(b_open0 | b_open1) << 1)) << j;
   }
   // not counted yet: the last pair of an odd number of pairs, and the last, single point of an
   // odd number of points (the second lane of its record is a copy)
@@ -402,6 +432,77 @@ __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restr
     if ((late >> j) & 1ull) c += (in0 ? 1 : 0) + ((two && in1) ? 1 : 0);
     if (open0 & me) c += exact(lds + j * kPairStride) ? 1 : 0;
     if (two && (open1 & me)) c += exact(lds + j * kPairStride + 1) ? 1 : 0;
+  }
+  return c;
+}
+
+// The same count for launches whose pairs are mostly unrelated (loop-closure candidates): there
+// a hypothesis' inliers are little more than its own sample points, so most (hypothesis, staged
+// pair) combinations can be dismissed by left_open -- were it not that a wavefront's 64
+// hypotheses x 4 sample points land in more than half of a pair's staged records.  Hence:
+// `mine` has bit j set when staged pair j of this chunk holds one of the lane's own sample
+// points; those (lane, pair) combinations are NOT counted here -- the launch that solved the
+// hypotheses has counted them and started the hypothesis' count there -- and
+//   1. every staged pair goes through left_open, lanes with the pair in `mine` left out, which
+//      yields a scalar bit mask of the pairs that keep a lane (a few in a hundred);
+//   2. those pairs go through screen_pair as usual, again without the `mine` lanes.
+// Every other (lane, staged pair) is either counted in 2 with the decisions of screen_pair /
+// the fp64 path or dismissed for sure in 1: the same count.
+template <bool RECT, class Exact>
+__device__ __forceinline__ int count_chunk_inliers_sparse(const float *__restrict__ lds, int cnt,
+                                                          const Hyp32 &h, Screen32 sc, double thr2,
+                                                          unsigned long long mine, Exact &&exact) {
+  const f2 nthr2f = splat(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
+      __builtin_bit_cast(int, -(float)thr2))));
+  const f2 aT = splat(sc.aT), ca = splat(sc.ca), cb = splat(sc.cb);
+  const int full = cnt >> 1;          // pairs of two real points
+  const int recs = (cnt + 1) >> 1;    // staged records (the last may hold one point and its copy)
+  int c = 0;
+  unsigned long long need = 0ull;     // wave-uniform, scalar registers
+  // 32 staged pairs per half of `mine`: the lane's bit of pair j is a 32-bit and + compare
+  const unsigned mine_half[2] = {(unsigned)mine, (unsigned)(mine >> 32)};
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    const unsigned word = mine_half[half];
+    const int end = min(recs, 32 * half + 32);
+    int j = 32 * half;
+    for (; j + 1 < end; j += 2) {
+      const unsigned bit = 1u << (j & 31);
+      const unsigned long long a = left_open(lds + j * kPairStride, h, nthr2f, aT, ca, cb) &
+                                   ~__builtin_amdgcn_ballot_w64((word & bit) != 0u);
+      const unsigned long long b = left_open(lds + (j + 1) * kPairStride, h, nthr2f, aT, ca, cb) &
+                                   ~__builtin_amdgcn_ballot_w64((word & (bit << 1)) != 0u);
+      need |= ((unsigned long long)any_lane(a) | ((unsigned long long)any_lane(b) << 1)) << j;
+    }
+    if (j < end) {
+      const unsigned long long a = left_open(lds + j * kPairStride, h, nthr2f, aT, ca, cb) &
+                                   ~__builtin_amdgcn_ballot_w64((word & (1u << (j & 31))) != 0u);
+      need |= (unsigned long long)any_lane(a) << j;
+    }
+  }
+  // undecided points are only noted (per lane, one bit per staged pair and point) and taken
+  // through the fp64 path at the end, from one place
+  const unsigned long long me = 1ull << __lane_id();
+  unsigned long long und0 = 0ull, und1 = 0ull;
+  while (need) {
+    const int k = __builtin_ctzll(need);
+    need &= need - 1ull;
+    bool in0, in1;
+    unsigned long long open0, open1;
+    screen_pair<RECT>(lds + k * kPairStride, h, nthr2f, aT, ca, cb, in0, in1, open0, open1);
+    const bool two = k < full, other = !((mine >> k) & 1ull);
+    c += (other && in0 ? 1 : 0) + ((other && two && in1) ? 1 : 0);
+    und0 |= (other && (open0 & me)) ? 1ull << k : 0ull;
+    und1 |= (other && two && (open1 & me)) ? 1ull << k : 0ull;
+  }
+#pragma clang loop unroll(disable)
+  for (int pt = 0; pt < 2; ++pt) {
+    unsigned long long u = pt ? und1 : und0;
+    while (u) {
+      const int k = __builtin_ctzll(u);
+      u &= u - 1ull;
+      c += exact(lds + k * kPairStride + pt) ? 1 : 0;
+    }
   }
   return c;
 }

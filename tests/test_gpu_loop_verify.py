@@ -293,3 +293,53 @@ def test_keyframe_points_use_float32_keypoints_like_cv2_keypoint(golden):
         assert (got == ref).mean() > 0.99 and np.abs(got - ref).max() <= 2.5e-7 * np.abs(ref).max()
         checked += 1
     assert checked >= 2
+
+
+def test_counting_schemes_give_the_same_consensus():
+    """The consensus count of pair verification dismisses most (hypothesis, point) combinations
+    of unrelated keyframes by the left image alone and takes each hypothesis' own sample points
+    from the launch that solved it (tune knob 2 = 1, the default here; 3: the front-end too);
+    knob 2 = 2 screens every combination and 0 evaluates all of them in fp64.  Same counts, so
+    the same winners, iteration numbers, masks and poses -- on related and unrelated pairs,
+    odd and tiny match counts, pairs of one chunk and of many."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=200, n_features=(40, 1400), seed=12, clutter=0.5)
+    ids = [0, 1, 2, 3, 50, 51, 52, 120, 121, 199]
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in ids)]
+    st = TrackingFrontend(cam, n_iter_max=1).run(frames)
+    keyframes = [(st.frame(k)["links"], st.frame(k)["inlier_des_left"]) for k in range(len(ids))]
+    keyframes.append((keyframes[0][0][:5], keyframes[0][1][:5]))            # fewer rows than a sample needs spare
+    keyframes.append((keyframes[1][0][:129], keyframes[1][1][:129]))        # one point past a chunk of 128
+    pairs = np.array([(i, n) for n in range(len(keyframes)) for i in range(len(keyframes)) if i != n], dtype=np.int64)
+    keys = ("ok", "n_matches", "n_inliers", "iterations", "Rt", "Rt_ransac", "mask")
+    fe_seq = StereoSequence(cam, n_frames=70, n_features=(300, 900), seed=3, clutter=0.6)
+    fe_frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (fe_seq.frame(k) for k in range(70))]
+    fe_keys = ("ransac_info", "pose_ransac", "pose_refined", "tm_mask")
+    ref = fe_ref = None
+    try:
+        for knob in (2, 1, 3, 0):
+            assert _lib.lib.slamhip_tune(2, knob) == 0
+            for min_inl in (10, 30):
+                ver = PairVerifier(cam, seed=4, min_inliers_loop=min_inl).set_keyframes(keyframes)
+                res = ver.verify(pairs)
+                got = {k: np.array(res[k]).copy() for k in keys}
+                if knob == 2:
+                    ref = ref or {}
+                    ref[min_inl] = got
+                    assert 4 <= got["ok"].sum() < len(pairs) // 2
+                for k in keys:
+                    np.testing.assert_array_equal(got[k], ref[min_inl][k], err_msg=f"knob {knob}: {k}")
+            for F in (70, 9):        # rounds with the merged tail; the single pass of short calls
+                h = TrackingFrontend(cam, n_iter_max=700, seed=8).run(fe_frames[:F]).to_host()
+                got = {k: h[k].copy() for k in fe_keys}
+                if knob == 2:
+                    fe_ref = fe_ref or {}
+                    fe_ref[F] = got
+                for k in fe_keys:
+                    np.testing.assert_array_equal(got[k], fe_ref[F][k], err_msg=f"front-end, knob {knob}: {k}")
+    finally:
+        _lib.lib.slamhip_tune(2, 1)

@@ -1,10 +1,12 @@
 """One-off soak of the loop-closure pair verification for run-to-run determinism:
 random keyframe sets (3..40 keyframes of 40..900 links), all pairs, both matcher modes,
-random gates; verify() twice, every output identical.  python tools/soak_verify.py [cases]"""
+random gates; verify() twice and once more with every combination of hypothesis and point
+screened (tune knob 2 = 2) instead of the sparse counting scheme, every output identical.
+python tools/soak_verify.py [cases [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from slam_amd import CameraModel
+from slam_amd import CameraModel, _lib
 from slam_amd.backend.optimizers.loop_verify import PairVerifier
 from slam_amd.backend.tracking.frontend import TrackingFrontend
 from slam_amd.utils.synth import StereoSequence
@@ -29,12 +31,16 @@ for case in range(cases):
                        n_iter_max=int(rng.choice([100, 1500])),
                        frame_cross_check=bool(rng.integers(2))).set_keyframes(keyframes)
     a, b = ver.verify(pairs), ver.verify(pairs)
+    _lib.lib.slamhip_tune(2, 2)
+    c = ver.verify(pairs)
+    _lib.lib.slamhip_tune(2, 1)
     ok = True
-    for k in ("ok", "Rt", "Rt_ransac", "n_matches", "n_inliers", "iterations", "out_off"):
-        ok = ok and np.array_equal(a[k], b[k], equal_nan=True)
-    for p in np.flatnonzero(a["ok"])[:20]:
-        ma, mb = a.pair_matches(int(p)), b.pair_matches(int(p))
-        ok = ok and all(np.array_equal(ma[k], mb[k]) for k in ma)
+    for other in (b, c):
+        for k in ("ok", "Rt", "Rt_ransac", "n_matches", "n_inliers", "iterations", "out_off"):
+            ok = ok and np.array_equal(a[k], other[k], equal_nan=True)
+        for p in np.flatnonzero(a["ok"])[:20]:
+            ma, mb = a.pair_matches(int(p)), other.pair_matches(int(p))
+            ok = ok and all(np.array_equal(ma[k], mb[k]) for k in ma)
     if not ok:
         bad += 1
         print(f"MISMATCH case {case}: KF={KF} step={step}", flush=True)
