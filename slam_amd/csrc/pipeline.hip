@@ -715,13 +715,15 @@ __device__ __forceinline__ void ransac_count_item(
     const int cnt = min(kPtsPerChunk, span1 - p0);
     if (p0 != span0) __syncthreads();
     Screen32 sc = {0.0f, 0.0f, 0.0f};
+    unsigned s2max_chunk = 0u;   // MODE 3: bits of the largest staged s^2 of the chunk
     if (screened) {
-      unsigned umax = 0u;
+      unsigned umax = 0u, s2max = 0u;
       for (int j = threadIdx.x; 2 * j < cnt; j += 64) {
         const size_t a = base + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
-        stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b, umax);
+        stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b, umax, s2max);
       }
       sc = make_screen(h32, wave_max_u32(umax), (float)thresh, (float)thr2);
+      if (MODE == 3) s2max_chunk = wave_max_u32(s2max);
     } else {
       for (int i = threadIdx.x; i < cnt; i += 64) {
         const size_t g = base + i;
@@ -746,7 +748,7 @@ __device__ __forceinline__ void ransac_count_item(
           const int d = s4[k] - p0;
           if (d >= 0 && d < cnt) mine |= 1ull << (d >> 1);
         }
-        c += count_chunk_inliers_sparse<true>(ldsf, cnt, h32, sc, thr2, mine, exact);
+        c += count_chunk_inliers_sparse<true>(ldsf, cnt, h32, sc, thr2, s2max_chunk, mine, exact);
       } else if (screened)
         c += count_chunk_inliers_screened<MODE >= 2>(ldsf, cnt, h32, sc, thr2, exact);
       else

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(64) void ransac_score_kernel(
     float *ldsf = reinterpret_cast<float *>(lds);
     for (int j = threadIdx.x; 2 * j < cnt; j += blockDim.x) {
       const size_t a = (size_t)p0 + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
-      stage_pair(ldsf + j * kPairStride, reinterpret_cast<const float *>(pts), mL, mR, a, b, umax);
+      unsigned s2max = 0u;   // not needed here
+      stage_pair(ldsf + j * kPairStride, reinterpret_cast<const float *>(pts), mL, mR, a, b, umax, s2max);
     }
     umax = wave_max_u32(umax);
   } else {

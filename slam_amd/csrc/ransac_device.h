@@ -237,12 +237,12 @@ __device__ __forceinline__ void make_hyp32(const double (&PL)[12], const double 
 
 // Writes the staged record of the point pair (a, b) (b = a when the chunk has an
 // odd point count; the caller ignores that second lane) and raises umax_bits to the
-// bit pattern of the largest |pixel coordinate| of the pair; a NaN coordinate has
-// the largest pattern of all and stays.
+// bit pattern of the largest |pixel coordinate| of the pair (a NaN coordinate has
+// the largest pattern of all and stays) and s2max_bits to that of the largest staged s^2.
 __device__ __forceinline__ void stage_pair(float *__restrict__ o, const float *__restrict__ X,
                                            const float *__restrict__ mL,
                                            const float *__restrict__ mR, size_t a, size_t b,
-                                           unsigned &umax_bits) {
+                                           unsigned &umax_bits, unsigned &s2max_bits) {
   const size_t idx[2] = {a, b};
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -253,6 +253,7 @@ __device__ __forceinline__ void stage_pair(float *__restrict__ o, const float *_
     o[0 + k] = x; o[2 + k] = y; o[4 + k] = z;
     o[6 + k] = ul; o[8 + k] = vl; o[10 + k] = ur; o[12 + k] = vr;
     o[14 + k] = (s <= kScreenMaxS) ? (s * s) * 1.000001f : __builtin_inff();   // NaN lands here too
+    s2max_bits = max(s2max_bits, __float_as_uint(o[14 + k]));                 // not negative: bits order like floats
     umax_bits = max(max(umax_bits, __float_as_uint(fabsf(ul))), __float_as_uint(fabsf(vl)));
     umax_bits = max(max(umax_bits, __float_as_uint(fabsf(ur))), __float_as_uint(fabsf(vr)));
   }
@@ -337,25 +338,48 @@ __device__ __forceinline__ void screen_pair(const float *__restrict__ rec, const
   }
 }
 
-// The left camera alone (rectified pair): the lanes (of those active) for which this cannot put
-// both points of the staged pair outside for sure.  dL and T are those of screen_pair, whose
-// verdict "outside for sure" is max(dL, dR) > T: dL > T implies it.  For a lane not in the
-// result screen_pair counts nothing and leaves nothing undecided.  19 instructions against 33.
-__device__ __forceinline__ unsigned long long left_open(const float *__restrict__ rec, const Hyp32 &h,
-                                                        f2 nthr2f, f2 aT, f2 ca, f2 cb) {
+// The left camera alone (rectified pair), one comparison per point: the lanes (of those active)
+// for which this cannot put both points of the staged pair outside for sure.
+//
+// screen_pair's verdict "outside for sure" is max(dL, dR) > T with, for the left camera,
+//     dL = fl(n w2 + inner),   T = fl(aT w2 + C),   n = -thr^2,  C = fl(s^2 ca + cb)
+// (w2 = fl(w w), inner = fl(dx dx + fl(dy dy)): the same fp32 numbers here and there).  This
+// evaluates D = fl(m w2 + inner) > Cx instead, with two constants of the hypothesis and chunk
+// (left_gate):  m <= n - aT (1 + 2.1 eps)  and  Cx >= Cmax (1 + 4 eps) + 4 eta,  Cmax >= every
+// C of the chunk, eta = 2^-150.  Proof that D > Cx implies dL > T (finite operands; eps = 2^-24):
+// with the real numbers E_L = n w2 + inner, E_T = aT w2 + C >= 0, E_D = m w2 + inner, rounding
+// is monotonic and Cx is a float, so D > Cx gives E_D > Cx; then
+//     E_L - E_T >= E_D + 2.1 eps aT w2 - C > 4 eps Cmax + 4 eta + 2.1 eps aT w2
+//                                          >= (2 eps E_T + 2 eta) / (1 - eps),
+// which is E_L (1 - eps) - eta > E_T (1 + eps) + eta, and dL >= E_L (1 - eps) - eta (E_L > 0),
+// T <= E_T (1 + eps) + eta.  Infinite or NaN operands: w2 infinite makes D -inf or NaN (open);
+// inner infinite with w2 finite makes D = dL = +inf > T; a NaN or infinite Cx (anything outside
+// the screen's domain) compares false, so everything stays open and screen_pair decides.
+// For a lane not in the result screen_pair counts nothing and leaves nothing undecided.
+struct LeftGate {
+  float m, cx;
+};
+__device__ __forceinline__ LeftGate left_gate(Screen32 sc, float thr2f, unsigned s2max_bits) {
+  LeftGate g;
+  // fl(thr^2 + aT) >= (thr^2 + aT)(1 - eps), times 1.000001 rounded: >= (thr^2 + aT)(1 + 8e-7)
+  // >= thr^2 + aT (1 + 2.1 eps)
+  g.m = -((thr2f + sc.aT) * 1.000001f);
+  // cb >= 1e-18 (make_screen), so the factor also covers 4 eta
+  g.cx = __builtin_fmaf(__uint_as_float(s2max_bits), sc.ca, sc.cb) * 1.000001f;
+  return g;
+}
+__device__ __forceinline__ unsigned long long left_open(const float *__restrict__ rec, const Hyp32 &h, f2 m,
+                                                        f2 cx) {
   const f2 *q = reinterpret_cast<const f2 *>(rec);
   const f2 X = q[0], Y = q[1], Z = q[2];
-  const f2 C = fma2(q[7], ca, cb);
   const f2 x = fma2(splat(h.PL[0]), X, fma2(splat(h.PL[1]), Y, fma2(splat(h.PL[2]), Z, splat(h.PL[3]))));
   const f2 y = fma2(splat(h.PL[4]), X, fma2(splat(h.PL[5]), Y, fma2(splat(h.PL[6]), Z, splat(h.PL[7]))));
   const f2 w = fma2(splat(h.PL[8]), X, fma2(splat(h.PL[9]), Y, fma2(splat(h.PL[10]), Z, splat(h.PL[11]))));
   const f2 dx = fma2(q[3], w, -x), dy = fma2(q[4], w, -y);
   const f2 w2 = w * w;
-  const f2 dL = fma2(nthr2f, w2, fma2(dx, dx, dy * dy));   // exactly screen_pair's
-  const f2 TL = fma2(aT, w2, C);
+  const f2 D = fma2(m, w2, fma2(dx, dx, dy * dy));
   const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
-  // a NaN on either side (anything outside the screen's domain) compares false: stays open
-  return active & ~(__builtin_amdgcn_ballot_w64(dL.x > TL.x) & __builtin_amdgcn_ballot_w64(dL.y > TL.y));
+  return active & ~(__builtin_amdgcn_ballot_w64(D.x > cx.x) & __builtin_amdgcn_ballot_w64(D.y > cx.y));
 }
 
 // 1 when the lane mask is not empty, in a scalar register (written as a select the compiler
@@ -451,10 +475,13 @@ __device__ __forceinline__ int count_chunk_inliers_screened(const float *__restr
 template <bool RECT, class Exact>
 __device__ __forceinline__ int count_chunk_inliers_sparse(const float *__restrict__ lds, int cnt,
                                                           const Hyp32 &h, Screen32 sc, double thr2,
-                                                          unsigned long long mine, Exact &&exact) {
+                                                          unsigned s2max_bits, unsigned long long mine,
+                                                          Exact &&exact) {
   const f2 nthr2f = splat(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
       __builtin_bit_cast(int, -(float)thr2))));
   const f2 aT = splat(sc.aT), ca = splat(sc.ca), cb = splat(sc.cb);
+  const LeftGate gate = left_gate(sc, (float)thr2, s2max_bits);
+  const f2 gm = splat(gate.m), gc = splat(gate.cx);
   const int full = cnt >> 1;          // pairs of two real points
   const int recs = (cnt + 1) >> 1;    // staged records (the last may hold one point and its copy)
   int c = 0;
@@ -468,14 +495,14 @@ __device__ __forceinline__ int count_chunk_inliers_sparse(const float *__restric
     int j = 32 * half;
     for (; j + 1 < end; j += 2) {
       const unsigned bit = 1u << (j & 31);
-      const unsigned long long a = left_open(lds + j * kPairStride, h, nthr2f, aT, ca, cb) &
+      const unsigned long long a = left_open(lds + j * kPairStride, h, gm, gc) &
                                    ~__builtin_amdgcn_ballot_w64((word & bit) != 0u);
-      const unsigned long long b = left_open(lds + (j + 1) * kPairStride, h, nthr2f, aT, ca, cb) &
+      const unsigned long long b = left_open(lds + (j + 1) * kPairStride, h, gm, gc) &
                                    ~__builtin_amdgcn_ballot_w64((word & (bit << 1)) != 0u);
       need |= ((unsigned long long)any_lane(a) | ((unsigned long long)any_lane(b) << 1)) << j;
     }
     if (j < end) {
-      const unsigned long long a = left_open(lds + j * kPairStride, h, nthr2f, aT, ca, cb) &
+      const unsigned long long a = left_open(lds + j * kPairStride, h, gm, gc) &
                                    ~__builtin_amdgcn_ballot_w64((word & (1u << (j & 31))) != 0u);
       need |= (unsigned long long)any_lane(a) << j;
     }

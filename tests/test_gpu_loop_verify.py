@@ -343,3 +343,58 @@ def test_counting_schemes_give_the_same_consensus():
                     np.testing.assert_array_equal(got[k], fe_ref[F][k], err_msg=f"front-end, knob {knob}: {k}")
     finally:
         _lib.lib.slamhip_tune(2, 1)
+
+
+def test_counting_schemes_agree_on_points_at_the_threshold():
+    """A keyframe pair made so that a quarter of the hypotheses (samples of exact points) is the
+    true motion to rounding and the other points sit at the threshold distance from their
+    projections, times 1 +- {1e-7 ... 5e-3}: across the band the packed-fp32 screen leaves
+    undecided and on both sides of it.  The sparse counting scheme (tune knob 2 = 1 / 3), the
+    plain screen (2) and fp64 alone (0) must count the same."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    cam = CameraModel.kitti_like()
+    fx, fy, cx, cy = cam.K[0, 0], cam.K[1, 1], cam.K[0, 2], cam.K[1, 2]
+    base = -cam.M_right[0, 3]
+    rng = np.random.default_rng(77)
+    n = 700
+    Z = rng.uniform(6.0, 60.0, n)
+    X = np.column_stack([rng.uniform(-0.8, 0.8, n) * Z, rng.uniform(-0.2, 0.2, n) * Z, Z])
+
+    def links_of(P):
+        u, v = fx * P[:, 0] / P[:, 2] + cx, fy * P[:, 1] / P[:, 2] + cy
+        return np.column_stack([u, u - fx * base / P[:, 2], v])
+
+    ang = 0.03
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    t = np.array([0.1, -0.02, -0.9])
+    la, lb = links_of(X), links_of(X @ R.T + t)
+    # float32 pixels are what the verifier keeps; the points it triangulates come from la
+    la, lb = la.astype(np.float32).astype(np.float64), lb.astype(np.float32).astype(np.float64)
+    thr = 1.5
+    moved = rng.random(n) < 0.3
+    factor = 1.0 + rng.choice([1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 2e-3, 3e-3, 5e-3], n) * rng.choice([-1.0, 1.0], n)
+    phi = rng.uniform(0, 2 * np.pi, n)
+    which = rng.integers(0, 3, n)          # move: the left x and the row / the right x alone / the left x alone
+    d = thr * factor
+    lb[moved & (which == 0), 0] += (d * np.cos(phi))[moved & (which == 0)]
+    lb[moved & (which == 0), 2] += (d * np.sin(phi))[moved & (which == 0)]
+    lb[moved & (which == 1), 1] += d[moved & (which == 1)]
+    lb[moved & (which == 2), 0] -= d[moved & (which == 2)]
+    des = rng.integers(0, 256, (n, 61), dtype=np.uint8)
+    keyframes = [(la, des), (lb, des.copy())]
+    ref = None
+    try:
+        for knob in (0, 2, 1, 3):
+            assert _lib.lib.slamhip_tune(2, knob) == 0
+            for seed in (1, 2):
+                res = PairVerifier(cam, seed=seed, min_inliers_loop=20, n_iter_max=600).set_keyframes(keyframes).verify([(0, 1), (1, 0)])
+                got = {k: np.array(res[k]).copy() for k in ("ok", "n_inliers", "iterations", "Rt_ransac", "mask")}
+                if knob == 0:
+                    ref = ref or {}
+                    ref[seed] = got
+                    assert got["ok"].all() and 0.6 * n < got["n_inliers"].min() and got["n_inliers"].max() < 0.95 * n
+                for k in got:
+                    np.testing.assert_array_equal(got[k], ref[seed][k], err_msg=f"knob {knob} seed {seed}: {k}")
+    finally:
+        _lib.lib.slamhip_tune(2, 1)
