@@ -2,8 +2,9 @@
 launch schemes: random sequences (2..40 frames, every fourth 64..90; 60..2500 features per image, both
 cross-check flags, random iteration caps), each run twice and once more with each of the
 other RANSAC launch schemes forced (rounds; rounds with the merged tail) and once with the
-descriptor rows packed in front of the stereo matcher and once with the sorts as launches of
-their own; every valid output row must be identical bit for bit.
+descriptor rows packed in front of the stereo matcher, once with the sorts as launches of
+their own, once with pair verification's consensus counting scheme and once with the consensus
+counted in fp64 alone; every valid output row must be identical bit for bit.
 python tools/soak_frontend.py [cases [seed]]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -68,11 +69,16 @@ for case in range(cases):
     _lib.lib.slamhip_tune(5, 2)          # the sorts as launches of their own (bitonic network)
     g = snapshot(fe.run(inp), F)
     _lib.lib.slamhip_tune(5, 0)
-    r1, r2, r3, r4, r5 = same(a, b), same(a, c), same(a, d), same(a, e), same(a, g)
-    if r1 is not True or r2 is not True or r3 is not True or r4 is not True or r5 is not True:
+    _lib.lib.slamhip_tune(2, 3)          # the consensus counting scheme of pair verification
+    h = snapshot(fe.run(inp), F)
+    _lib.lib.slamhip_tune(2, 0)          # consensus counting in fp64 alone
+    i = snapshot(fe.run(inp), F)
+    _lib.lib.slamhip_tune(2, 1)
+    r1, r2, r3, r4, r5, r6, r7 = same(a, b), same(a, c), same(a, d), same(a, e), same(a, g), same(a, h), same(a, i)
+    if not all(r is True for r in (r1, r2, r3, r4, r5, r6, r7)):
         bad += 1
         print(f"MISMATCH case {case}: F={F} nfeat={nfeat} rerun={r1} rounds={r2} tail={r3} packed={r4} "
-              f"sort={r5}", flush=True)
+              f"sort={r5} sparse count={r6} fp64 count={r7}", flush=True)
     if case % 5 == 0:
         print(f"case {case} ok so far (F={F}, features {nfeat}), mismatches {bad}", flush=True)
 print(f"done: {cases} cases, {bad} mismatches")
