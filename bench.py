@@ -390,14 +390,16 @@ def bench_loop_verify(args, rank, world, dist, red_dev="cuda"):
     for k in range(KF):
         fr = st.frame(k)
         keyframes.append((fr["links"], fr["inlier_des_left"]))
-    pairs = np.array([(i, n) for n in range(KF) for i in range(n)], dtype=np.int64)[rank::world]
-    ver = PairVerifier(cam, seed=rank).set_keyframes(keyframes)
-    ver.verify(pairs).verified_matches()                        # warm-up: sizes the workspace
+    every = np.array([(i, n) for n in range(KF) for i in range(n)], dtype=np.int64)
+    # samples are keyed by the pair's index in the whole list: N ranks together give the results of one
+    pairs, ids = every[rank::world], np.arange(len(every))[rank::world]
+    ver = PairVerifier(cam, seed=0).set_keyframes(keyframes)
+    ver.verify(pairs, pair_ids=ids).verified_matches()          # warm-up: sizes the workspace
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
-    res = ver.verify(pairs)
+    res = ver.verify(pairs, pair_ids=ids)
     vm = res.verified_matches()        # matches + inlier masks of the verified pairs, on the host
     torch.cuda.synchronize()
     if dist is not None:

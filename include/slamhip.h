@@ -462,6 +462,10 @@ typedef struct slamhip_verify_args {
   /* cross_check only */
   const int32_t *d_tobase;               /* n_pairs (device) */
   int32_t n_tout_total, reserved;
+  /* The device sampler keys pair p's samples by (seed, d_pair_ids[p]), or by (seed, p) when this
+   * is NULL.  A pair list cut into shards (one per GPU) passes each pair's index in the whole
+   * list here: every pair then draws the samples, and gets the result, of the uncut run. */
+  const int64_t *d_pair_ids;             /* n_pairs (device) or NULL */
 } slamhip_verify_args;
 
 size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *args);

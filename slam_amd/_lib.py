@@ -118,6 +118,7 @@ class VerifyArgs(C.Structure):
         ("d_tm_mask", _vp), ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_info", _vp),
         ("d_workspace", _vp), ("workspace_bytes", _sz),
         ("d_tobase", _vp), ("n_tout_total", _i32), ("reserved", _i32),
+        ("d_pair_ids", _vp),
     ]
 
 

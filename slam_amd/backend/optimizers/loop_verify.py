@@ -124,13 +124,17 @@ class PairVerifier:
                     "des": kernels.to_device(des, torch.uint8)}
         return self
 
-    def verify(self, pairs) -> dict:
+    def verify(self, pairs, pair_ids=None) -> dict:
         """pairs: (P,2) int array of (candidate, current) keyframe indices.
         Returns a VerifyResult: ok (P,), Rt (P,3,4) candidate->current pose,
         Rt_ransac, n_matches, n_inliers, iterations, out_off (P+1,) on the host,
         and the flat per-match arrays query_idx / train_idx / dist / mask (rows
         out_off[p]:out_off[p+1] belong to pair p), copied from the device on
-        first use."""
+        first use.
+        pair_ids (optional, (P,) int): each pair's index in the whole candidate
+        list when `pairs` is one shard of it (e.g. whole[rank::world] with
+        pair_ids = arange(len(whole))[rank::world]): the sampler is keyed by
+        (seed, pair id), so the shards together give the results of the uncut list."""
         if self._kf is None:
             raise RuntimeError("call set_keyframes first")
         kf = self._kf
@@ -176,6 +180,13 @@ class PairVerifier:
         a.seed = self.seed
         a.cross_check = int(self.frame_cross_check)
         a.d_tobase, a.n_tout_total = d_tobase.data_ptr(), int(tobase[-1])
+        d_ids = None
+        if pair_ids is not None:
+            ids = np.ascontiguousarray(pair_ids, dtype=np.int64).reshape(-1)
+            if len(ids) != P:
+                raise ValueError("pair_ids must have one entry per pair")
+            d_ids = kernels.to_device(ids, torch.int64)
+            a.d_pair_ids = d_ids.data_ptr()
         a.d_xyz = out["xyz"].data_ptr()
         a.d_tm_query, a.d_tm_train = out["tm_query"].data_ptr(), out["tm_train"].data_ptr()
         a.d_tm_dist, a.d_tm_mask = out["tm_dist"].data_ptr(), out["tm_mask"].data_ptr()

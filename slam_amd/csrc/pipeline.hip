@@ -487,6 +487,7 @@ struct RansacParams {
   unsigned long long seed;
   long long pair0;  // index of the launch's first pair among the pairs of this call (sample table row)
   long long seq0;   // index of this call's first pair in the caller's numbering of the whole job (sampler)
+  const long long *pair_ids;   // or, when not null: pair_ids[pair0 + p] is pair p's number in the whole job
 };
 
 // grid (pairs, slots).  A launch covers `slots` consecutive blocks of kHypPerRound
@@ -574,7 +575,8 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
     } else {
       // keyed by the pair's index in the whole job, so that batching, chunking and
       // sharding over ranks do not change a pair's samples
-      const unsigned long long sp_ = (unsigned long long)(prm.seq0 + prm.pair0 + p);
+      const unsigned long long sp_ = (unsigned long long)(prm.pair_ids != nullptr ? prm.pair_ids[prm.pair0 + p]
+                                                                                   : prm.seq0 + prm.pair0 + p);
       unsigned long long r = splitmix64(prm.seed ^ (sp_ << 32) ^ (unsigned long long)it);
       for (int k = 0; k < 4; ++k) {
         int c = 0;
@@ -1276,6 +1278,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   prm.seed = a->seed;
   prm.pair0 = 0;
   prm.seq0 = a->first_pair;
+  prm.pair_ids = nullptr;
   rc = run_pair_ransac(a->d_off_left, tcount, cx, cpl, cpr, a->d_samples, prm, F - 1, a->max_left,
                        a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st,
                        /*merge_tail=*/true);
@@ -1442,6 +1445,7 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
     prm.seed = a->seed;
     prm.pair0 = 0;
     prm.seq0 = c0;
+    prm.pair_ids = a->d_pair_ids != nullptr ? reinterpret_cast<const long long *>(a->d_pair_ids) + c0 : nullptr;
     rc = run_pair_ransac(ob, tcount + c0, cx, cpl, cpr, nullptr, prm, np, a->max_q,
                          a->d_pose_ransac + 12 * (size_t)c0, a->d_tm_mask,
                          a->d_info + 8 * (size_t)c0, ransac_ws, st, /*merge_tail=*/false,
