@@ -435,3 +435,30 @@ def test_a_pair_list_dealt_over_ranks_gives_the_results_of_the_whole_list():
     assert not np.array_equal(np.array(unkeyed["Rt_ransac"]), ref["Rt_ransac"][1::3])
     with pytest.raises(ValueError):
         ver.verify(every[:4], pair_ids=[0, 1])
+
+
+def test_pairs_with_more_matches_than_a_sample_index_field_holds():
+    """The sparse counting scheme keeps a hypothesis' sample indices in 16 bits each; a call with
+    more than 65535 rows per keyframe counts the plain way, with the same results as with the
+    scheme switched off."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    cam = CameraModel.kitti_like()
+    rng = np.random.default_rng(5)
+    n = 66000
+
+    def kf():
+        x = rng.uniform(50, 1200, n); y = rng.uniform(5, 365, n)
+        return (np.column_stack([x, x - rng.uniform(2, 60, n), y]), rng.integers(0, 256, (n, 32), dtype=np.uint8))
+    ver = PairVerifier(cam, seed=1, n_iter_max=300).set_keyframes([kf(), kf()])
+    got = {}
+    try:
+        for knob in (1, 2):
+            _lib.lib.slamhip_tune(2, knob)
+            res = ver.verify([(0, 1)])
+            got[knob] = {k: np.array(res[k]).copy() for k in ("ok", "n_matches", "n_inliers", "iterations", "Rt_ransac")}
+    finally:
+        _lib.lib.slamhip_tune(2, 1)
+    assert got[1]["n_matches"][0] == n and 1 <= got[1]["iterations"][0] <= 300
+    for k in got[1]:
+        np.testing.assert_array_equal(got[1][k], got[2][k], err_msg=k)
