@@ -477,6 +477,7 @@ __device__ __forceinline__ int count_chunk_inliers_sparse(const float *__restric
                                                           const Hyp32 &h, Screen32 sc, double thr2,
                                                           unsigned s2max_bits, unsigned long long mine,
                                                           Exact &&exact) {
+  static_assert(RECT, "left_open relies on the one threshold both cameras of a rectified pair share");
   const f2 nthr2f = splat(__builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(
       __builtin_bit_cast(int, -(float)thr2))));
   const f2 aT = splat(sc.aT), ca = splat(sc.ca), cb = splat(sc.cb);
