@@ -261,6 +261,15 @@ def test_pair_list_longer_than_one_chunk_with_a_short_tail():
     sure = [k for k in range(len(base)) if res["ok"][:32768][kind[:32768] == k].mean() > 0.999]
     assert sure, "no keyframe pair verifies reliably"
     assert all(res["ok"][32768:][kind[32768:] == k].all() for k in sure)
+    # sampler keys across the chunk boundary: the list's own numbering changes nothing, and keys
+    # that give every copy of a keyframe pair the number of its first copy make the copies equal
+    first = {k: np.array(res[k]).copy() for k in ("ok", "n_inliers", "iterations", "Rt_ransac")}
+    keyed = ver.verify(pairs, pair_ids=np.arange(n_pairs))
+    for k in first:
+        np.testing.assert_array_equal(np.array(keyed[k]), first[k], err_msg=k)
+    same = ver.verify(pairs, pair_ids=kind)
+    for k in first:
+        np.testing.assert_array_equal(np.array(same[k]), first[k][:len(base)][kind], err_msg=k)
 
 
 def test_keyframe_points_use_float32_keypoints_like_cv2_keypoint(golden):
