@@ -156,7 +156,7 @@ def cpu_baseline(q: np.ndarray, t: np.ndarray, target_s: float = 10.0):
     }, idx2, dist2
 
 
-def bench_frontend(args, rank, world, dist, red_dev="cuda"):
+def bench_frontend(args, rank, world, dist, red_dev="cuda", deferred=None):
     """Secondary measurement (BASELINE.json configs[2]/[3] shape): the whole per-frame
     front-end (stereo match, filter, triangulate, temporal match, adaptive P3P
     RANSAC, LM refinement) over `--frames` synthetic KITTI-shaped frames per GPU,
@@ -178,11 +178,7 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
     inputs = fe.upload(frames)
 
     def step():
-        res = fe.run(inputs)
-        if dist is not None:   # device-side record assembly + one gather onto rank 0's GPU
-            blob = sharding.pack_result(res, (0, F), (0, F - 1), rank * F, rank * (F - 1))
-            sharding.gather_records(blob, dst=0)
-        return res
+        return fe.run(inputs)
 
     for _ in range(5):       # a pass is well under a millisecond: a few of them before the clock is read
         res = step()
@@ -196,10 +192,49 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+    elapsed = max_over_ranks(elapsed)
+    # The hand-over, timed on its own: every rank packs its records on the device (one
+    # kernel) and ONE gather brings them to rank 0 -- once per sequence in a real run, so it
+    # is not part of the per-pass rate above.
+    gather = None
+    if dist is not None:
+        def pack():
+            return sharding.pack_result(res, (0, F), (0, F - 1), rank * F, rank * (F - 1))
+        blob = pack()
+        sharding.gather_records(blob, dst=0)             # warm: communicator, buffers
+        reps = 3
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            blob = pack()
+        torch.cuda.synchronize()
+        pack_s = max_over_ranks((time.perf_counter() - t0) / reps)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            got = sharding.gather_records(blob, dst=0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        gather_s = max_over_ranks((time.perf_counter() - t0) / reps)
+        total = None
+        if rank == 0:
+            total = int(sum(g.numel() for g in got))
+            head = got[world - 1][:40].cpu().numpy().view(np.int64)   # the last rank's header, as a check
+            assert int(head[0]) == F and int(head[2]) == (world - 1) * F, head
+        gather = {"pack_ms": pack_s * 1e3, "gather_ms": gather_s * 1e3, "record_bytes_this_rank": int(blob.numel()),
+                  "bytes_on_rank0": total,
+                  "GBps_into_rank0": None if not total else total * (world - 1) / world / gather_s / 1e9,
+                  "note": "one variable-length byte record per rank (poses, links, inlier descriptors, matches, "
+                          "masks), packed by one kernel, sizes by a tiny all_gather, payload by one gather "
+                          "onto rank 0's GPU; done once per sequence, outside the timed passes"}
     if rank != 0:
         return None
     h = res.to_host()
@@ -230,10 +265,12 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
         "unit": "frames/s",
         "ms_per_frame": elapsed / (F * args.frontend_steps) * 1e3,
         "workload": f"{F} synthetic KITTI-shaped stereo frames per GPU (1226x370, 1500 AKAZE-like "
-                    f"features per image, 61-byte descriptors), full front-end per frame, features given"
-                    + ("" if world == 1 else "; per-frame records (poses, links, inlier descriptors, "
-                       "matches, masks) packed on the device and gathered onto rank 0 once per pass"),
+                    f"features per image, 61-byte descriptors), full front-end per frame, features given",
         "steps": args.frontend_steps,
+        "ms_per_pass": elapsed / args.frontend_steps * 1e3,
+        "hand_over": gather,
+        "value_with_one_hand_over_per_pass": None if gather is None else
+        F * world / (elapsed / args.frontend_steps + (gather["pack_ms"] + gather["gather_ms"]) * 1e-3),
         "stereo_inliers_mean": float(h["st_count"][:F].mean()),
         "temporal_matches_mean": float(info[:, 5].mean()),
         "ransac_inlier_ratio_mean": float((info[:, 1] / np.maximum(info[:, 5], 1)).mean()),
@@ -312,8 +349,10 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda"):
                            "temporal_matches_mean": float(i2[:, 5].mean()),
                            "ransac_iterations_mean": float(i2[:, 2].mean())}
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_frontend(cam, frames, fe)
-        out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        def cpu_leg():      # run by main() after every GPU section, so that the GPU work is contiguous
+            out["cpu_baseline"] = cpu_baseline_frontend(cam, frames, fe)
+            out["gpu_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        deferred.append(cpu_leg)
     return out
 
 
@@ -451,6 +490,43 @@ def cpu_baseline_frontend(cam, frames, fe, target_s=10.0):
             "ransac_inliers_mean": float(c["info"][:n - 1, 1].mean())}
 
 
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: start N copies of this
+    script, one per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run
+    sets them), before anything in this process has touched the GPU.  The children share
+    this process's stdout, and only rank 0 prints, so its JSON line is the output.  Returns
+    0 if every rank ended with 0, else the first failing rank's code; ranks still running
+    30 s after another has failed are ended (by their own process ids)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", str(port)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(sys.argv[0])] + sys.argv[1:], env=env))
+    rc, deadline, pending = 0, None, set(range(n))
+    while pending:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0:
+                print(f"bench.py: rank {r} ended with code {code}", file=sys.stderr, flush=True)
+                rc = rc or code
+                deadline = deadline or time.monotonic() + 30.0
+        if deadline is not None and time.monotonic() > deadline:
+            for r in pending:
+                procs[r].kill()
+            deadline = time.monotonic() + 1e9
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -473,10 +549,12 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (this process never touches the GPU)
+        raise SystemExit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU")
     # Rehearsal knobs (one-GPU box): SLAMHIP_BENCH_BACKEND=gloo and
@@ -500,6 +578,22 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     red_dev = "cuda" if backend == "nccl" else "cpu"
+    # how many ranks the collective backend really joined (a sum of ones over the group, on
+    # device tensors with nccl = RCCL), which devices they sit on, and the library's version
+    ranks_seen, devices, rccl_version = 1, None, None
+    if dist is not None:
+        ones = torch.ones(1, dtype=torch.int64, device=red_dev)
+        dist.all_reduce(ones)
+        ranks_seen = int(ones.item())
+        prop = torch.cuda.get_device_properties(local_rank)
+        mine = f"rank {rank}: cuda:{local_rank} {prop.name} {getattr(prop, 'uuid', '')}".strip()
+        devices = [None] * world
+        dist.all_gather_object(devices, mine)
+        if backend == "nccl":
+            try:
+                rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:  # noqa: BLE001
+                rccl_version = None
 
     from slam_amd import _lib, kernels
     from slam_amd.utils.synth import matcher_workload
@@ -575,7 +669,10 @@ def main():
             "value": compares * args.steps * world / elapsed,
             "unit": "compares/s",
             "n_gpus": world,
-            "dist_backend": backend if dist is not None else None,
+            "dist_backend": backend if dist is not None else "none (single process)",
+            "ranks_seen": ranks_seen,
+            "rank_devices": devices,
+            "rccl_version": rccl_version,
             "steps": args.steps,
             "warmup": args.warmup,
             "preheat_s": args.preheat,
@@ -591,11 +688,31 @@ def main():
                                    "brute-force Hamming kNN(k=2) + ratio test, one pair per GPU",
                        "nq": NQ, "nt": NT, "desc_bytes": DESC_BYTES, "ratio": RATIO,
                        "parallelism": f"independent pairs x{world}"},
-            "roofline": dict(matcher_roofline(mfma, compares, kernel_s, n_launch),
-                             kernel_us_method=f"HIP events on the launch stream around {PROBE_REPEAT} back-to-back "
-                                              f"launches of the kernel per call, {n_launch} calls",
-                             kernel_us_one_launch_per_event_pair=kernel_s_single * 1e6),
+            # headline figures from ONE launch per event pair (the two event records are inside
+            # the interval, so this is an upper bound of the launch and comparable with what
+            # rocprofv3 --kernel-trace reports); the back-to-back figure is kept beside it
+            "roofline": dict(matcher_roofline(mfma, compares, kernel_s_single, n_launch),
+                             kernel_us_method=f"HIP events on the launch stream around one launch of the kernel per "
+                                              f"call, {n_launch} calls (includes the two event records)",
+                             kernel_us_back_to_back=kernel_s * 1e6,
+                             frac_back_to_back=matcher_roofline(mfma, compares, kernel_s, n_launch)["frac"],
+                             back_to_back_method=f"{PROBE_REPEAT} identical launches between the two events"),
         }
+        # north_star words its target in popcount units (>= 50 % of the popcount-bound roofline):
+        # the step's rate against the two popcount ceilings, whichever kernel family ran
+        v = line["value"] / world
+        line["vs_popcount_roofline"] = {
+            "per_gpu_compares_per_sec": v,
+            "vs_uniform_2_cycle_valu": v / (UNIFORM_PEAK_LANE_OPS / OPS_PER_COMPARE),
+            "uniform_2_cycle_valu_compares_per_sec": UNIFORM_PEAK_LANE_OPS / OPS_PER_COMPARE,
+            "uniform_source": "MI355X_MICROARCH.md: 1024 SIMDs x 32 lanes/clock x 2.4 GHz = 78.6 Tlane-op/s, "
+                              "32 lane-ops (16 xor + 16 popcount) per 61-byte compare",
+            "vs_survey_estimate": v / 1.2e12,
+            "survey_estimate_compares_per_sec": 1.2e12,
+            "survey_source": "256 CUs x 64 lanes x 2.4 GHz / 32 lane-ops per compare",
+            "note": "above 1 means faster than any xor+popcount kernel can be on this chip: the matrix-core "
+                    "matcher does the compare as an FP4 contraction instead" if mfma else
+                    "the popcount kernel family"}
     # The secondary sections exchange records between ranks.  The primary measurement is
     # complete at this point: if a section fails on one rank (the others would then wait in
     # a collective for ever) or does not finish in time, rank 0 still prints the line, with
@@ -612,9 +729,10 @@ def main():
     watchdog.start()
     failed = {}
     frontend = loop_verify = None
+    deferred = []           # CPU legs, run last
     try:
         if args.frames >= 2:
-            frontend = bench_frontend(args, rank, world, dist, red_dev)
+            frontend = bench_frontend(args, rank, world, dist, red_dev, deferred)
     except Exception as e:  # noqa: BLE001
         failed["frontend"] = repr(e)
     try:
@@ -639,6 +757,8 @@ def main():
             line["loop_verify"] = loop_verify
         if failed:
             line["secondary_sections_failed"] = failed
+        for leg in deferred:
+            leg()
         if world == 1 and not args.no_cpu_baseline:
             res = cpu_baseline(q_np, t_np)
             if res is not None:

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SLAMHIP_VERSION 101 /* 0.1.1 */
+#define SLAMHIP_VERSION 102 /* 0.1.2: struct_size leads the two argument structs; d_samples for pair verification */
 
 enum {
   SLAMHIP_OK = 0,
@@ -340,6 +340,13 @@ int slamhip_ransac_replay(const int32_t *d_counts, int h, int n_points, double p
 /* d_off_left[f]; counts are in d_st_count / d_ransac_info.                  */
 /* ------------------------------------------------------------------------- */
 typedef struct slamhip_frontend_args {
+  uint32_t struct_size;                  /* = sizeof(slamhip_frontend_args) of the header the caller was
+                                            built against.  Every entry point that takes this struct
+                                            returns SLAMHIP_EINVAL (0 for the *_bytes queries) when it
+                                            differs from the library's own: fields have been added over
+                                            the versions, and a shorter struct read as the longer one
+                                            would hand the kernels stray pointers.  Zero-initialise the
+                                            struct, set this, then the fields in use. */
   /* inputs (device unless noted) */
   int32_t n_frames;                      /* F >= 1 */
   int32_t n_left_total, n_right_total;   /* rows of the concatenated arrays */
@@ -441,6 +448,8 @@ int slamhip_frontend_pack_record(const slamhip_frontend_args *args, int frame_lo
 /* n_tout_total = sum of d_tcnt.                                             */
 /* ------------------------------------------------------------------------- */
 typedef struct slamhip_verify_args {
+  uint32_t struct_size;                  /* = sizeof(slamhip_verify_args); checked like
+                                            slamhip_frontend_args.struct_size */
   int32_t n_rows_total;                  /* rows of the per-keyframe arrays */
   int32_t desc_bytes, desc_stride;
   int32_t n_pairs, n_out_total, max_q, max_t;
@@ -466,6 +475,12 @@ typedef struct slamhip_verify_args {
    * is NULL.  A pair list cut into shards (one per GPU) passes each pair's index in the whole
    * list here: every pair then draws the samples, and gets the result, of the uncut run. */
   const int64_t *d_pair_ids;             /* n_pairs (device) or NULL */
+  /* Optional (n_pairs, n_iter_max, 4) int32 on the device: the idx4 sequence of
+   * ransac_pnp_pair1's rng.choice(N, 4) (frontend/geometry/pnp.py:126, called from
+   * loop_closure.py:215-216) for every pair, as indices into the pair's sorted matches; values
+   * are clamped to [0, N).  Iteration i of pair p uses row (p, i).  NULL = device sampler.  With
+   * it a CPU run of the reference's loop on the same sequence can be compared count for count. */
+  const int32_t *d_samples;
 } slamhip_verify_args;
 
 size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *args);

@@ -114,10 +114,12 @@ def run(cam, frames, pixel_thresh=4.0, disparity_min=1.2, samples=None, refine=T
 
 def consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loop=60,
                         p_success=0.99999, n_iter_max=1500, rng=None, knn2=None, refine=True,
-                        cross_check=False):
+                        cross_check=False, samples=None, solver=None):
     """LoopClosure.consensus_pnp_match (backend/optimizers/loop_closure.py:167-235)
     up to the refined pose.  kf = (links (n,3) [x_left, x_right, y], des_left);
-    cross_check = LoopClosure's frame_cross_check (the matcher of :192)."""
+    cross_check = LoopClosure's frame_cross_check (the matcher of :192).
+    samples (n_iter_max, 4): the idx4 sequence of the RANSAC loop instead of rng.choice
+    (pnp.py:126); solver(obj4, img4): the minimal solver instead of the oracle's P3P."""
     links_i, des_i = kf_cand
     links_n, des_n = kf_curr
     # frame_data, :152-164: cv2.KeyPoint(x, y, 1) keeps float32 coordinates
@@ -134,7 +136,7 @@ def consensus_pnp_match(cam, kf_cand, kf_curr, pixel_thresh=1.5, min_inliers_loo
     ptsL = kpL_n[ti].astype(np.float32)
     ptsR = kpR_n[ti].astype(np.float32)
     out.update(P3D=P3D, ptsL=ptsL, ptsR=ptsR)
-    r = ransac_loop(cam, P3D, ptsL, ptsR, pixel_thresh, None, None, p_success, n_iter_max, rng)  # :215-216
+    r = ransac_loop(cam, P3D, ptsL, ptsR, pixel_thresh, samples, solver, p_success, n_iter_max, rng)  # :215-216
     out.update(r)
     if r["mask"].sum() < min_inliers_loop:                              # :218-219
         return out

@@ -83,6 +83,7 @@ _i32, _u64 = C.c_int32, C.c_uint64
 class FrontendArgs(C.Structure):
     """Mirror of `slamhip_frontend_args` (include/slamhip.h), field for field."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("n_frames", _i32), ("n_left_total", _i32), ("n_right_total", _i32),
         ("max_left", _i32), ("max_right", _i32), ("desc_bytes", _i32), ("desc_stride", _i32),
         ("d_kp_left", _vp), ("d_kp_right", _vp), ("d_des_left", _vp), ("d_des_right", _vp),
@@ -101,10 +102,15 @@ class FrontendArgs(C.Structure):
         ("first_pair", C.c_int64),
     ]
 
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)
+
 
 class VerifyArgs(C.Structure):
     """Mirror of `slamhip_verify_args` (include/slamhip.h), field for field."""
     _fields_ = [
+        ("struct_size", C.c_uint32),
         ("n_rows_total", _i32), ("desc_bytes", _i32), ("desc_stride", _i32),
         ("n_pairs", _i32), ("n_out_total", _i32), ("max_q", _i32), ("max_t", _i32),
         ("d_kp_left", _vp), ("d_kp_right", _vp), ("d_des", _vp),
@@ -118,8 +124,12 @@ class VerifyArgs(C.Structure):
         ("d_tm_mask", _vp), ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_info", _vp),
         ("d_workspace", _vp), ("workspace_bytes", _sz),
         ("d_tobase", _vp), ("n_tout_total", _i32), ("reserved", _i32),
-        ("d_pair_ids", _vp),
+        ("d_pair_ids", _vp), ("d_samples", _vp),
     ]
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self.struct_size = C.sizeof(self)
 
 
 SIGNATURES["slamhip_verify_workspace_bytes"] = (_sz, [C.POINTER(VerifyArgs)])

@@ -19,7 +19,8 @@ from ..._lib import lib, check, VerifyArgs
 
 class VerifyResult(dict):
     """Result of PairVerifier.verify.  The per-pair arrays (ok, Rt, Rt_ransac,
-    n_matches, n_inliers, iterations, out_off) are host arrays.  The per-match
+    n_matches, n_inliers, iterations, best_index, best_count, n_iter_required, out_off)
+    are host arrays.  The per-match
     arrays (query_idx, train_idx, dist, mask; and xyz per keyframe row) stay on
     the device until asked for: `res["mask"]` copies the whole array once,
     `res.pair_matches(p)` copies one pair, `res.verified_matches()` gathers the
@@ -124,7 +125,7 @@ class PairVerifier:
                     "des": kernels.to_device(des, torch.uint8)}
         return self
 
-    def verify(self, pairs, pair_ids=None) -> dict:
+    def verify(self, pairs, pair_ids=None, samples=None) -> dict:
         """pairs: (P,2) int array of (candidate, current) keyframe indices.
         Returns a VerifyResult: ok (P,), Rt (P,3,4) candidate->current pose,
         Rt_ransac, n_matches, n_inliers, iterations, out_off (P+1,) on the host,
@@ -134,7 +135,11 @@ class PairVerifier:
         pair_ids (optional, (P,) int): each pair's index in the whole candidate
         list when `pairs` is one shard of it (e.g. whole[rank::world] with
         pair_ids = arange(len(whole))[rank::world]): the sampler is keyed by
-        (seed, pair id), so the shards together give the results of the uncut list."""
+        (seed, pair id), so the shards together give the results of the uncut list.
+        samples (optional, (P, n_iter_max, 4) int): the idx4 sequence of every pair's RANSAC
+        loop (what rng.choice(N, 4, replace=False) returns at pnp.py:126), as indices into the
+        pair's sorted matches, instead of the device sampler: a CPU run of the reference's loop
+        on the same sequence is then comparable count for count."""
         if self._kf is None:
             raise RuntimeError("call set_keyframes first")
         kf = self._kf
@@ -187,6 +192,13 @@ class PairVerifier:
                 raise ValueError("pair_ids must have one entry per pair")
             d_ids = kernels.to_device(ids, torch.int64)
             a.d_pair_ids = d_ids.data_ptr()
+        d_samples = None
+        if samples is not None:
+            smp = np.ascontiguousarray(samples, dtype=np.int32)
+            if smp.shape != (P, self.n_iter_max, 4):
+                raise ValueError("samples must have shape (n_pairs, n_iter_max, 4)")
+            d_samples = kernels.to_device(smp, torch.int32)
+            a.d_samples = d_samples.data_ptr()
         a.d_xyz = out["xyz"].data_ptr()
         a.d_tm_query, a.d_tm_train = out["tm_query"].data_ptr(), out["tm_train"].data_ptr()
         a.d_tm_dist, a.d_tm_mask = out["tm_dist"].data_ptr(), out["tm_mask"].data_ptr()
@@ -209,6 +221,7 @@ class PairVerifier:
             "ok": ok, "Rt": out["pose_refined"].cpu().numpy().reshape(-1, 3, 4)[:P],
             "Rt_ransac": out["pose_ransac"].cpu().numpy().reshape(-1, 3, 4)[:P],
             "n_matches": n_matches, "n_inliers": n_inl, "iterations": info[:, 2],
+            "best_index": info[:, 0], "best_count": info[:, 1], "n_iter_required": info[:, 3],
             "out_off": obase,
         }
         return VerifyResult(host, out, O, N)

@@ -129,6 +129,8 @@ class FrontendResult:
     # ------------------------------------------------------------ per-frame views
     def frame(self, f: int) -> dict:
         h = self.to_host()
+        if "st_desc" not in h and self.inputs.host is None:
+            h = self.to_host(gathers=True)      # no host copy of the inputs to gather from: fetch the rows
         b = int(self.inputs.off_left[f])
         m = int(h["st_count"][f])
         sl = slice(b, b + m)
@@ -284,6 +286,11 @@ class TrackingFrontend:
                 inp = self.upload(packed[a:b + 1])
                 ev = torch.cuda.Event()
                 ev.record(s_in)
+            # allocated on the side stream, read by the pass on the main one: tell the caching
+            # allocator, so that the memory is not handed out again while that pass is still
+            # queued should the result be dropped early
+            for t in (inp.d_off_left, inp.d_off_right, inp.kp_left, inp.kp_right, inp.des_left, inp.des_right):
+                t.record_stream(main)
             return inp, ev
 
         results = []

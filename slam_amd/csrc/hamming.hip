@@ -1183,7 +1183,8 @@ int slamhip_hamming_knn2_ratio_static(const uint8_t *d_query, int nq, const uint
   if (nq < 0 || nt < 0) return SLAMHIP_EINVAL;
   if (!d_keep && nq > 0) return SLAMHIP_EINVAL;
   if (nq > SLAMHIP_STATIC_MAX_ROWS || nt > SLAMHIP_STATIC_MAX_ROWS) return SLAMHIP_EUNSUPPORTED;
-  if (desc_bytes < 1 || desc_bytes > SLAMHIP_MAX_DESC_BYTES) return SLAMHIP_EINVAL;
+  if (desc_bytes < 1) return SLAMHIP_EINVAL;
+  if (desc_bytes > SLAMHIP_MAX_DESC_BYTES) return SLAMHIP_EUNSUPPORTED;   // as the workspace call answers
   // the plan of any call within the row limit fits the array (checked again inside run_knn2)
   if (make_plan(nq, nt, 1, nq, nt, desc_bytes).total > kStaticScratchBytes) return SLAMHIP_EUNSUPPORTED;
   void *ws = static_scratch_for_current_device();

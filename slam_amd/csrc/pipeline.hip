@@ -1111,7 +1111,7 @@ bool invert3x3(const double *K, double *o) {
 extern "C" {
 
 size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *a) {
-  if (!a || a->n_frames < 1 || a->n_left_total < 0 || a->n_right_total < 0 || a->desc_bytes < 1 ||
+  if (!a || a->struct_size != sizeof(slamhip_frontend_args) || a->n_frames < 1 || a->n_left_total < 0 || a->n_right_total < 0 || a->desc_bytes < 1 ||
       a->desc_bytes > SLAMHIP_MAX_DESC_BYTES)
     return 0;
   return make_layout(a).total;
@@ -1119,7 +1119,8 @@ size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *a) {
 
 int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   SLAMHIP_BEGIN();
-  if (!a || a->n_frames < 1 || a->n_left_total < 0 || a->n_right_total < 0) return SLAMHIP_EINVAL;
+  if (!a || a->struct_size != sizeof(slamhip_frontend_args)) return SLAMHIP_EINVAL;   // built against another header
+  if (a->n_frames < 1 || a->n_left_total < 0 || a->n_right_total < 0) return SLAMHIP_EINVAL;
   if (a->desc_bytes < 1 || a->desc_stride < a->desc_bytes) return SLAMHIP_EINVAL;
   if (a->desc_bytes > SLAMHIP_MAX_DESC_BYTES || a->n_frames > 65535 ||
       a->max_left > SLAMHIP_MAX_TRAIN_ROWS || a->max_right > SLAMHIP_MAX_TRAIN_ROWS)
@@ -1322,7 +1323,7 @@ static size_t verify_knn_bytes(const slamhip_verify_args *a) {
 }
 
 size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
-  if (!a || a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0 || a->desc_bytes < 1 ||
+  if (!a || a->struct_size != sizeof(slamhip_verify_args) || a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0 || a->desc_bytes < 1 ||
       a->desc_bytes > SLAMHIP_MAX_DESC_BYTES)
     return 0;
   const int W = slamhip_packed_words(a->desc_bytes);
@@ -1346,7 +1347,8 @@ size_t slamhip_verify_workspace_bytes(const slamhip_verify_args *a) {
 
 int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
   SLAMHIP_BEGIN();
-  if (!a || a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0) return SLAMHIP_EINVAL;
+  if (!a || a->struct_size != sizeof(slamhip_verify_args)) return SLAMHIP_EINVAL;   // built against another header
+  if (a->n_rows_total < 0 || a->n_pairs < 0 || a->n_out_total < 0) return SLAMHIP_EINVAL;
   if (a->desc_bytes < 1 || a->desc_stride < a->desc_bytes || a->n_iter_max < 1 ||
       a->refine_iters < 0 || a->max_q < 0 || a->max_t < 0)
     return SLAMHIP_EINVAL;
@@ -1446,7 +1448,9 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
     prm.pair0 = 0;
     prm.seq0 = c0;
     prm.pair_ids = a->d_pair_ids != nullptr ? reinterpret_cast<const long long *>(a->d_pair_ids) + c0 : nullptr;
-    rc = run_pair_ransac(ob, tcount + c0, cx, cpl, cpr, nullptr, prm, np, a->max_q,
+    // a given sample table is indexed by the pair's place in this call's list
+    const int32_t *samples = a->d_samples != nullptr ? a->d_samples + (size_t)c0 * a->n_iter_max * 4 : nullptr;
+    rc = run_pair_ransac(ob, tcount + c0, cx, cpl, cpr, samples, prm, np, a->max_q,
                          a->d_pose_ransac + 12 * (size_t)c0, a->d_tm_mask,
                          a->d_info + 8 * (size_t)c0, ransac_ws, st, /*merge_tail=*/false,
                          /*mostly_unrelated=*/true);

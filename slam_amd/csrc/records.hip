@@ -54,8 +54,9 @@ __device__ __forceinline__ void put64(uint8_t *dst, unsigned long long v) {
   put32(dst + 4, (uint32_t)(v >> 32));
 }
 
-// grid.y: [0, nf) = owned frame, [nf, nf + np) = owned pair, nf + np = head, counts and the
-// per-pair fixed fields
+// Segment y, dealt over grid.y (a launch has at most 65535 rows of blocks; a batch of 65535
+// frames has twice as many segments): [0, nf) = owned frame, [nf, nf + np) = owned pair,
+// nf + np = head, counts and the per-pair fixed fields
 __global__ __launch_bounds__(256) void pack_record_kernel(
     RecordLayout L, int nf, int np, int frame_lo, int pair_lo, long long first_frame, long long first_pair, int D,
     int W, const int32_t *__restrict__ off_left, const long long *__restrict__ st_out_off,
@@ -66,8 +67,8 @@ __global__ __launch_bounds__(256) void pack_record_kernel(
     const int32_t *__restrict__ tm_train, const int32_t *__restrict__ tm_dist, const uint8_t *__restrict__ tm_mask,
     const double *__restrict__ pose_refined, const double *__restrict__ pose_ransac,
     const int32_t *__restrict__ info, uint8_t *__restrict__ out) {
-  const int y = blockIdx.y;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int y = blockIdx.y; y < nf + np + 1; y += gridDim.y) {
   if (y < nf) {
     const long long o0 = st_out_off[y];
     const int n = (int)(st_out_off[y + 1] - o0);
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(256) void pack_record_kernel(
     }
     for (int j = tid; j < np * 8; j += stride) put32(out + L.info + 4 * (long long)j, (uint32_t)info[(size_t)pair_lo * 8 + j]);
   }
+  }
 }
 
 }  // namespace
@@ -143,7 +145,7 @@ int slamhip_frontend_pack_record(const slamhip_frontend_args *a, int frame_lo, i
       pair_hi > (a->n_frames > 0 ? a->n_frames - 1 : 0) || stereo_rows < 0 || temporal_rows < 0)
     return SLAMHIP_EINVAL;
   const int nf = frame_hi - frame_lo, np = pair_hi - pair_lo;
-  if (nf + np + 1 > 65535) return SLAMHIP_EUNSUPPORTED;
+  if (a->struct_size != sizeof(slamhip_frontend_args)) return SLAMHIP_EINVAL;
   const int D = a->desc_bytes, W = slamhip_packed_words(D);
   const RecordLayout L = make_layout(nf, np, stereo_rows, temporal_rows, D);
   if (!d_record || record_bytes < (size_t)L.total) return SLAMHIP_EWORKSPACE;
@@ -153,7 +155,8 @@ int slamhip_frontend_pack_record(const slamhip_frontend_args *a, int frame_lo, i
       !a->d_ransac_info)
     return SLAMHIP_EINVAL;
   const int per_segment = a->max_left > 0 ? a->max_left : 1;
-  const dim3 grid(slamhip_ceil_div(per_segment, 256) < 8 ? slamhip_ceil_div(per_segment, 256) : 8, nf + np + 1);
+  const dim3 grid(slamhip_ceil_div(per_segment, 256) < 8 ? slamhip_ceil_div(per_segment, 256) : 8,
+                  nf + np + 1 < 65535 ? nf + np + 1 : 65535);
   hipLaunchKernelGGL(pack_record_kernel, grid, dim3(256), 0, (hipStream_t)stream, L, nf, np, frame_lo, pair_lo,
                      (long long)first_frame, (long long)first_pair, D, W, a->d_off_left,
                      (const long long *)d_st_out_off, (const long long *)d_tm_out_off, a->d_st_left, a->d_st_right,

@@ -32,7 +32,7 @@ def test_binding_table_matches_header():
 
 def test_version_and_strerror_without_gpu():
     from slam_amd import _lib
-    assert _lib.lib.slamhip_version() >= 101
+    assert _lib.lib.slamhip_version() >= 102
     assert _lib.strerror(0) == "ok"
     assert "workspace" in _lib.strerror(_lib.EWORKSPACE)
     # argument validation happens before any device work
@@ -73,3 +73,43 @@ def test_header_is_plain_c_and_cxx(tmp_path):
         r = subprocess.run([cc, *flags, "-Wall", "-Wextra", "-Werror", "-fsyntax-only",
                             "-I", os.path.join(root, "include"), str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_argument_structs_match_the_header_and_are_size_checked(tmp_path):
+    """The ctypes mirrors of the two argument structs have the C compiler's size and field
+    offsets, they fill in struct_size themselves, and the entry points refuse a struct built
+    against another header (a different struct_size) before touching any pointer in it."""
+    import ctypes as C
+    import shutil
+    import subprocess
+    from slam_amd import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    probes = {"slamhip_frontend_args": ("struct_size", "n_frames", "d_samples", "d_workspace", "first_pair"),
+              "slamhip_verify_args": ("struct_size", "n_rows_total", "seed", "d_tobase", "d_pair_ids", "d_samples")}
+    body = "".join(f'printf("{s} %zu\\n", sizeof({s}));\n' + "".join(
+        f'printf("{s}.{f} %zu\\n", offsetof({s}, {f}));\n' for f in fields) for s, fields in probes.items())
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "slamhip.h"\nint main(void) {\n' + body + "return 0; }\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in (("slamhip_frontend_args", _lib.FrontendArgs), ("slamhip_verify_args", _lib.VerifyArgs)):
+        assert C.sizeof(cls) == int(out[cname])
+        for f in probes[cname]:
+            assert getattr(cls, f).offset == int(out[f"{cname}.{f}"]), (cname, f)
+        assert cls().struct_size == C.sizeof(cls)
+    a = _lib.FrontendArgs()
+    a.n_frames, a.desc_bytes, a.desc_stride, a.n_iter_max = 2, 61, 61, 10
+    assert _lib.lib.slamhip_frontend_workspace_bytes(C.byref(a)) > 0
+    a.struct_size -= 8                              # what a caller built against the previous header passes
+    assert _lib.lib.slamhip_frontend_workspace_bytes(C.byref(a)) == 0
+    assert _lib.lib.slamhip_frontend_batch(C.byref(a), None) == _lib.EINVAL
+    assert _lib.lib.slamhip_frontend_pack_record(C.byref(a), 0, 1, 0, 0, 0, 0, None, None, 0, 0, None, 0, None) == _lib.EINVAL
+    v = _lib.VerifyArgs()
+    v.desc_bytes = v.desc_stride = 61
+    v.n_iter_max = 10
+    assert _lib.lib.slamhip_verify_workspace_bytes(C.byref(v)) > 0
+    v.struct_size = 0                               # a zero-initialised struct of a caller that never heard of the field
+    assert _lib.lib.slamhip_verify_workspace_bytes(C.byref(v)) == 0
+    assert _lib.lib.slamhip_verify_pairs(C.byref(v), None) == _lib.EINVAL

@@ -7,6 +7,8 @@ import torch
 from oracle import pipeline_oracle as po
 from oracle import slam_oracle as so
 
+from _verify_helpers import _assert_same_consensus, _cpu_loop_on_device_poses, _idx4_table
+
 pytestmark = pytest.mark.gpu
 
 
@@ -57,6 +59,97 @@ def test_verify_pairs_against_oracle():
         truth = (B @ np.linalg.inv(A))[:3]
         assert np.abs(res["Rt"][p][:, 3] - truth[:, 3]).max() < 0.25
     assert 3 <= n_ok < len(pairs)          # near keyframes verify, far ones do not
+
+
+def test_verify_pairs_with_a_given_sample_sequence_count_for_count():
+    """d_samples on the pair-verification path: every pair runs the idx4 sequence it is given, so
+    the CPU loop on the same sequence is comparable iteration for iteration.  With the device's
+    own minimal solutions as hypotheses the CPU loop must reproduce winner, iteration count,
+    consensus count and mask exactly; with its own minimal solver (another root finder) the same
+    winner in nearly every pair, and then the same iteration count and the same mask to one point."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=120, n_features=900, seed=5, clutter=0.3)
+    kf_ids = [0, 2, 4, 60, 62, 118]
+    keyframes = []
+    for k in kf_ids:
+        f = seq.frame(k)
+        st = po.stereo_stage(cam, (f.kp_left, f.kp_right, f.des_left, f.des_right))
+        pl, pr = st["pix_left"].astype(np.float64), st["pix_right"].astype(np.float64)
+        keyframes.append((np.column_stack([pl[:, 0], pr[:, 0], (pl[:, 1] + pr[:, 1]) / 2]), st["inlier_des_left"]))
+    keyframes.append((keyframes[0][0][:30], keyframes[0][1][:30]))         # below the first gate: never sampled
+    pairs = np.array([(i, n) for n in range(len(keyframes)) for i in range(len(keyframes)) if i != n], dtype=np.int64)
+    n_iter = 300
+    counts = [len(keyframes[i][0]) for i, _ in pairs]                      # one match per candidate row
+    samples = _idx4_table(np.random.default_rng(9), counts, n_iter)
+    ver = PairVerifier(cam, seed=3, n_iter_max=n_iter).set_keyframes(keyframes)
+    res = ver.verify(pairs, samples=samples)
+    again = ver.verify(pairs, samples=samples, pair_ids=np.arange(len(pairs))[::-1].copy())
+    for k in ("best_index", "iterations", "n_inliers", "Rt"):             # the table, not the sampler keys, decides
+        np.testing.assert_array_equal(np.array(again[k]), np.array(res[k]))
+    n_ok = same_best = attempted = 0
+    for p, (i, n) in enumerate(pairs):
+        own, ref = _cpu_loop_on_device_poses(cam, keyframes[i], keyframes[n], samples[p], n_iter_max=n_iter)
+        sl = slice(int(res["out_off"][p]), int(res["out_off"][p + 1]))
+        if "P3D" not in ref:
+            assert res["iterations"][p] == 0 and not res["ok"][p]
+            continue
+        attempted += 1
+        _assert_same_consensus(cam, res, p, sl, ref)
+        assert bool(res["ok"][p]) == bool(ref["ok"])
+        if res["ok"][p]:
+            n_ok += 1
+            assert np.abs(res["Rt"][p] - ref["Rt"]).max() < 1e-7
+        if own["best_index"] == ref["best_index"]:
+            same_best += 1
+            assert own["iterations"] == res["iterations"][p]
+            assert (own["mask"] != res["mask"][sl]).sum() <= 1
+    assert n_ok >= 6 and attempted >= 30 and same_best >= attempted - 3
+    with pytest.raises(ValueError):
+        ver.verify(pairs, samples=samples[:, :10])
+
+
+def test_verify_reproduces_the_references_consensus_check_on_its_own_samples(golden):
+    """tests/golden/ref_consensus_flow.npz again, now with the reference run's own idx4 sequence:
+    the fixture records the seed its numpy.random.default_rng() calls were given, and the
+    reference draws rng.choice(N, 4, replace=False) once per iteration (pnp.py:126).  Fed that
+    sequence the device must end with the reference's mask (to one point: the fixture's
+    hypotheses came from the CPU minimal solver) and its relative pose."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    g = golden("ref_consensus_flow.npz")
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    ids = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("links_"))
+    keyframes = [(g[f"links_{k}"], g[f"des_{k}"]) for k in ids]
+    seed = int(g["seed0"])
+    checked = 0
+    for i, (curr, cand, gate, cc) in enumerate(g["cases"]):
+        calls = int(g[f"rng_calls_{i}"])
+        if calls == 0:
+            continue                                    # stopped at the first gate: no generator made
+        rng = np.random.default_rng(seed)
+        seed += calls
+        N = len(g[f"mask_{i}"])
+        ver = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i,
+                           frame_cross_check=bool(cc)).set_keyframes(keyframes)
+        if N == 0:                                      # second gate: the reference returned no mask
+            res = ver.verify(np.array([[ids.index(int(cand)), ids.index(int(curr))]], dtype=np.int64))
+            N = int(res["n_matches"][0])
+        samples = _idx4_table(rng, [N], ver.n_iter_max)
+        res = ver.verify(np.array([[ids.index(int(cand)), ids.index(int(curr))]], dtype=np.int64), samples=samples)
+        assert bool(res["ok"][0]) == bool(g[f"ok_{i}"]), f"case {i}"
+        if not res["ok"][0]:
+            continue
+        mask, ref_mask = res.pair_matches(0)["mask"], g[f"mask_{i}"]
+        assert len(mask) == len(ref_mask) and (mask != ref_mask).sum() <= 1, (i, (mask != ref_mask).sum())
+        T = np.eye(4)
+        T[:3] = res["Rt"][0]
+        D = np.linalg.inv(T) - g[f"delta_inv_{i}"]
+        assert np.abs(D).max() < (1e-6 if (mask == ref_mask).all() else 1e-3), (i, np.abs(D).max())
+        checked += 1
+    assert checked >= 2
 
 
 def test_verify_pairs_edge_cases():

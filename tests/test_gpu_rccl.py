@@ -139,6 +139,45 @@ def test_bench_multi_rank_path_runs_on_rccl_with_one_rank():
     assert line["dist_backend"] == "nccl"
 
 
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (here both
+    on the one GPU of the box, over gloo: RCCL rejects two ranks on one device), relays rank 0's
+    line and returns 0.  The line says how many ranks the collective backend joined and times
+    the record hand-over on its own."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SLAMHIP_BENCH_BACKEND="gloo", SLAMHIP_BENCH_ONE_DEVICE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
+                        "--warmup", "2", "--preheat", "0.05", "--frames", "12", "--frontend-steps", "1",
+                        "--envelope-frames", "0", "--lc-keyframes", "6", "--no-sweep", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import json
+    rows = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(rows) == 1, r.stdout[-2000:]
+    line = json.loads(rows[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["dist_backend"] == "gloo"
+    assert len(line["rank_devices"]) == 2
+    ho = line["frontend"]["hand_over"]
+    assert ho["gather_ms"] > 0 and ho["pack_ms"] > 0 and ho["bytes_on_rank0"] >= 2 * ho["record_bytes_this_rank"] * 0.5
+    assert line["loop_verify"]["value"] > 0
+
+
+def test_bench_launcher_returns_the_failing_ranks_code():
+    """A rank that fails makes the self-started run return non-zero (rank 1 raises in its
+    front-end section; rank 0 prints the line and both end with code 3)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(SLAMHIP_BENCH_BACKEND="gloo", SLAMHIP_BENCH_ONE_DEVICE="1", SLAMHIP_REHEARSE_FAIL_RANK="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_bench_failure.py"), "--gpus", "2",
+                        "--steps", "5", "--warmup", "2", "--preheat", "0.05", "--frames", "4",
+                        "--frontend-steps", "1", "--envelope-frames", "0", "--lc-keyframes", "0", "--no-sweep",
+                        "--no-cpu-baseline", "--section-timeout", "20"],
+                       capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
+    assert r.returncode != 0, (r.stdout[-1500:], r.stderr[-3000:])
+    import json
+    rows = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
+    assert len(rows) == 1 and json.loads(rows[0])["value"] > 0
+
+
 def test_bench_reports_a_failed_section_with_a_nonzero_exit_code():
     env = dict(os.environ, SLAMHIP_REHEARSE_FAIL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_bench_failure.py"), "--gpus", "1",

@@ -36,14 +36,32 @@ def _call_both(q_np, t_np, ratio=RATIO):
                                         ws.data_ptr(), ws.numel(), stream)
     assert rc == 0, _lib.strerror(rc)
     i_new, d_new, k_new = outputs()
+
+    def static_call():
+        return lib.slamhip_hamming_knn2_ratio_static(q.data_ptr(), nq, t.data_ptr(), nt, d, d, C.c_double(ratio),
+                                                     i_new.data_ptr(), d_new.data_ptr(), k_new.data_ptr(), stream)
+    global _WARM
+    if not _WARM:
+        # the first call on a device looks the scratch array's address up (hipGetSymbolAddress,
+        # once per device); the property below is about every call after it
+        assert static_call() == 0
+        _WARM = True
     torch.cuda.synchronize()
-    before = torch.cuda.memory_allocated(dev)
-    rc = lib.slamhip_hamming_knn2_ratio_static(q.data_ptr(), nq, t.data_ptr(), nt, d, d, C.c_double(ratio),
-                                               i_new.data_ptr(), d_new.data_ptr(), k_new.data_ptr(), stream)
+    # free device memory as the driver reports it (hipMemGetInfo): a hipMalloc / hipFree inside the
+    # library would move it; torch's own counter only sees torch's caching allocator
+    free_before, _ = torch.cuda.mem_get_info(dev)
+    torch_before = torch.cuda.memory_allocated(dev)
+    rc = static_call()
     assert rc == 0, _lib.strerror(rc)
+    free_during, _ = torch.cuda.mem_get_info(dev)       # kernels still in flight: nothing allocated and held
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated(dev) == before
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_during == free_before and free_after == free_before
+    assert torch.cuda.memory_allocated(dev) == torch_before
     return (i_ref, d_ref, k_ref), (i_new, d_new, k_new)
+
+
+_WARM = False
 
 
 def _workload(nq, nt, nbytes, seed):
@@ -69,6 +87,31 @@ def test_static_scratch_call_other_widths_and_small_inputs():
             assert torch.equal(a, b)
 
 
+def test_static_scratch_call_records_into_a_graph():
+    """Stream capture rejects allocation: the call records into a HIP graph (torch captures with
+    the error mode that makes any allocating runtime call on any thread fail the capture), and
+    the replayed graph gives the workspace call's results."""
+    from slam_amd import _lib
+    lib = _lib.lib
+    dev = torch.device("cuda", 0)
+    q_np, t_np = _workload(3000, 2500, 61, 9)
+    (i_ref, d_ref, k_ref), _ = _call_both(q_np, t_np)            # also the warm-up of the address lookup
+    q, t = torch.from_numpy(q_np).to(dev), torch.from_numpy(t_np).to(dev)
+    i2 = torch.full((3000, 2), -7, dtype=torch.int32, device=dev)
+    d2 = torch.full((3000, 2), -7, dtype=torch.int32, device=dev)
+    k = torch.full((3000,), 9, dtype=torch.uint8, device=dev)
+    g = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        rc = lib.slamhip_hamming_knn2_ratio_static(q.data_ptr(), 3000, t.data_ptr(), 2500, 61, 61,
+                                                   C.c_double(RATIO), i2.data_ptr(), d2.data_ptr(), k.data_ptr(),
+                                                   torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, _lib.strerror(rc)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(i2, i_ref) and torch.equal(d2, d_ref) and torch.equal(k, k_ref)
+
+
 def test_static_scratch_call_rejects_what_it_cannot_hold():
     from slam_amd import _lib
     lib = _lib.lib
@@ -88,6 +131,16 @@ def test_static_scratch_call_rejects_what_it_cannot_hold():
     assert lib.slamhip_hamming_knn2_ratio_static(q.data_ptr(), 16, t.data_ptr(), 16, 61, 61,
                                                  C.c_double(RATIO), i2.data_ptr(), d2.data_ptr(), None,
                                                  st) == _lib.EINVAL
+    # rows longer than the matcher supports: the code the workspace call gives for them
+    wide = torch.zeros((4, 200), dtype=torch.uint8, device=dev)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+    assert lib.slamhip_hamming_knn2_ratio(wide.data_ptr(), 4, wide.data_ptr(), 4, 200, 200, C.c_double(RATIO),
+                                          i2.data_ptr(), d2.data_ptr(), k.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          st) == _lib.EUNSUPPORTED
+    assert lib.slamhip_hamming_knn2_ratio_static(wide.data_ptr(), 4, wide.data_ptr(), 4, 200, 200,
+                                                 C.c_double(RATIO), *args) == _lib.EUNSUPPORTED
+    assert lib.slamhip_hamming_knn2_ratio_static(wide.data_ptr(), 4, wide.data_ptr(), 4, 0, 0,
+                                                 C.c_double(RATIO), *args) == _lib.EINVAL
     # empty query set: nothing to do, no error
     assert lib.slamhip_hamming_knn2_ratio_static(q.data_ptr(), 0, t.data_ptr(), 16, 61, 61,
                                                  C.c_double(RATIO), *args) == 0

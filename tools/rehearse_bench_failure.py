@@ -14,13 +14,13 @@ import bench  # noqa: E402
 _orig = bench.bench_frontend
 
 
-def _patched(args, rank, world, dist, red_dev="cuda"):
+def _patched(args, rank, world, dist, *more, **kw):
     if str(rank) == os.environ.get("SLAMHIP_REHEARSE_FAIL_RANK"):
         raise RuntimeError("rehearsed failure")
     if str(rank) == os.environ.get("SLAMHIP_REHEARSE_HANG_RANK"):
         while True:
             time.sleep(1.0)
-    return _orig(args, rank, world, dist, red_dev)
+    return _orig(args, rank, world, dist, *more, **kw)
 
 
 bench.bench_frontend = _patched
