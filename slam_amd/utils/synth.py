@@ -79,9 +79,13 @@ class StereoSequence:
 
     def __init__(self, cam: CameraModel, n_frames: int, n_features=1500, seed: int = 0,
                  nbytes: int = 61, clutter: float = 0.35, pixel_sigma: float = 0.5,
-                 bit_noise: float = 0.03):
+                 bit_noise: float = 0.03, landmark_density: float = 1.0):
         """`n_features` is the number of keypoints per image: an int, or a (lo, hi)
-        pair for a per-frame count drawn uniformly from [lo, hi]."""
+        pair for a per-frame count drawn uniformly from [lo, hi].
+        `landmark_density` scales the number of landmarks in the corridor.  Every frame
+        shows a random choice of the landmarks in view, so with many more in view than
+        shown (1.0: about 2.5 times as many) consecutive frames share about 40 % of their
+        true features; fewer landmarks make the frames share more of them."""
         if isinstance(n_features, (tuple, list)):
             self.n_features_range = (int(n_features[0]), int(n_features[1]))
             n_features = self.n_features_range[1]
@@ -93,7 +97,7 @@ class StereoSequence:
         rng = np.random.default_rng(seed)
         length = 120.0 + 0.8 * n_frames
         # landmark density chosen so that ~n_features*(1-clutter) are in view
-        n_land = int(n_features * (1 - clutter) * length / 45.0) + 64
+        n_land = int(n_features * (1 - clutter) * length / 45.0 * landmark_density) + 64
         self.land_xyz = np.column_stack([rng.uniform(-25, 25, n_land), rng.uniform(-3, 2, n_land),
                                          rng.uniform(2, length, n_land)])
         self.land_des = random_descriptors(rng, n_land, nbytes)
