@@ -391,6 +391,113 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda", deferred=None):
     return out
 
 
+def bench_sequence(args, rank, world, dist, red_dev="cuda"):
+    """BASELINE.json configs[3]: ONE sequence of `--sequence-frames` frames (2761 = KITTI-05) cut
+    into contiguous frame ranges, one per rank, each with its halo frame (pair p needs frames p
+    and p+1); every rank runs the front-end over its range, packs its records on the device, one
+    gather brings them to rank 0's GPU, and rank 0 copies them to the host and merges them into
+    the per-frame arrays the back-end's hand-over reads (run_slam.py:88-89).  Strong scaling:
+    the job is the same at every N.  Features resident in HBM when the clock starts."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking import sharding
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+
+    cam = CameraModel.kitti_like()
+    F = args.sequence_frames
+    lo, hi, (plo, phi), (flo, fhi) = sharding.frames_for_rank(F, world, rank)
+    seq = StereoSequence(cam, n_frames=F, n_features=1500, seed=55, clutter=0.63, landmark_density=0.58)
+    frames = []
+    for k in range(lo, hi):
+        f = seq.frame(k)
+        frames.append((f.kp_left, f.kp_right, f.des_left, f.des_right))
+    fe = TrackingFrontend(cam, seed=5)
+    inputs = fe.upload(frames) if frames else None
+    phases = {"front_end": 0.0, "pack": 0.0, "gather": 0.0, "to_host_and_merge": 0.0}
+
+    def lap(name, t0):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        phases[name] += t1 - t0
+        return t1
+
+    def one():
+        t = time.perf_counter()
+        if inputs is not None:
+            res = fe.run(inputs, first_pair=plo)
+            t = lap("front_end", t)
+            blob = sharding.pack_result(res, (flo - lo, fhi - lo), (plo - lo, phi - lo), flo, plo)
+        else:
+            blob = torch.from_numpy(sharding.pack_records([], [], 0, 0, 61)).cuda()
+        t = lap("pack", t)
+        got = sharding.gather_records(blob, dst=0) if dist is not None else [blob]
+        t = lap("gather", t)
+        merged = None
+        if rank == 0:
+            merged = sharding.merge_records([g.cpu().numpy() for g in got], F)
+            lap("to_host_and_merge", t)
+        return merged
+
+    one()
+    for k in phases:
+        phases[k] = 0.0
+    reps = 3
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        merged = one()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = (time.perf_counter() - t0) / reps
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank != 0:
+        return None
+    Rts = merged.relative_Rts
+    err = max(float(np.abs(Rts[p][:, 3] - seq.relative_pose(p + 1)[:, 3]).max()) for p in range(0, F - 1, 97))
+    return {"metric": "frontend_frames_per_sec", "value": F / elapsed, "unit": "frames/s", "scaling": "strong",
+            "frames": F, "seconds": elapsed, "pairs_on_rank0": phi - plo,
+            "workload": f"one {F}-frame synthetic sequence (KITTI-05 length, 1500 features per image, the "
+                        "reference's published match / inlier statistics) cut into one contiguous frame range "
+                        "per rank with a halo frame; front-end, device-side record packing, one gather onto rank "
+                        "0, copy to the host and merge into the per-frame arrays of the hand-over",
+            "rank0_phase_seconds": {k: v / reps for k, v in phases.items()},
+            "record_bytes_total": int(sum(len(merged.f[k].reshape(-1).view(np.uint8)) for k in merged.f)),
+            "poses": int(len(Rts)), "pose_error_vs_truth_max_m": err}
+
+
+def bench_online(args):
+    """The reference's own calling pattern (fill_database.py:140: one frame at a time): one
+    front-end call per new frame, two frames per call, features resident."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=2, n_features=1500, seed=3, clutter=0.63, landmark_density=0.58)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(2))]
+    fe = TrackingFrontend(cam)
+    inp = fe.upload(frames)
+    for _ in range(20):
+        fe.run(inp)
+    torch.cuda.synchronize()
+    reps = 300
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fe.run(inp)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"online_pair_us": dt * 1e6, "frames_per_sec": 1.0 / dt,
+            "note": "one pair of 1500-feature frames per call; the call is a chain of about ten dependent "
+                    "launches whose own durations add up to nearly all of it (profiles/r3/online_kernel_stats.csv): "
+                    "one block per frame or pair in most of them, so latency of the kernels, not launch "
+                    "overhead, is what a single-launch version would have to remove"}
+
+
 def bench_sweep(kernels, mfma=False):
     """Matcher alone at the other sizes the workload family covers (one pair,
     inputs resident): N in {2048, 4096, 8192} x D in {61 (AKAZE), 32 (ORB)}."""
@@ -578,6 +685,8 @@ def main():
     ap.add_argument("--no-sweep", action="store_true", help="skip the matcher size sweep")
     ap.add_argument("--section-timeout", type=float, default=300.0,
                     help="seconds the secondary sections (front-end, loop verification) may take together")
+    ap.add_argument("--sequence-frames", type=int, default=2761,
+                    help="frames of the one sequence sharded over the ranks by frame range (0 = skip)")
     ap.add_argument("--lc-keyframes", type=int, default=270,
                     help="keyframes of the secondary loop-closure verification measurement (0 = skip)")
     args = ap.parse_args()
@@ -770,6 +879,12 @@ def main():
             frontend = bench_frontend(args, rank, world, dist, red_dev, deferred)
     except Exception as e:  # noqa: BLE001
         failed["frontend"] = repr(e)
+    sequence = None
+    try:
+        if args.sequence_frames >= 2 and not failed:
+            sequence = bench_sequence(args, rank, world, dist, red_dev)
+    except Exception as e:  # noqa: BLE001
+        failed["sequence"] = repr(e)
     try:
         if args.lc_keyframes >= 2 and not failed:
             loop_verify = bench_loop_verify(args, rank, world, dist, red_dev)
@@ -788,6 +903,10 @@ def main():
             line["l2_matcher"] = bench_l2(kernels)
         if frontend is not None:
             line["frontend"] = frontend
+        if sequence is not None:
+            line["sequence_sharded"] = sequence
+        if world == 1 and args.frames >= 2 and not failed:
+            line["online"] = bench_online(args)
         if loop_verify is not None:
             line["loop_verify"] = loop_verify
         if failed:

@@ -708,7 +708,8 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
     // 4 waves x G groups of 32 queries per block; two groups unless one fills the last
     // block of a pair much better, or the registers do not allow more (32-word rows)
     int G = p.G;
-    if (G != 1 && G != 2) {
+    const bool four = G == 4 && p.W == 16;   // forced only: four groups per wave, one wave per SIMD
+    if (G != 1 && G != 2 && !four) {
       G = 2;
       const int idle2 = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 256) * 256 - max_nq;
       const int idle1 = slamhip_ceil_div(max_nq > 0 ? max_nq : 1, 128) * 128 - max_nq;

@@ -151,7 +151,7 @@ template <int W> __device__ __forceinline__ int row_swizzle(int row) {
 // any alignment; q_end / t_end one past the last byte of each array) instead of rows packed to W
 // dwords: no packing launch in front.
 template <int W, int G, bool BEST, int NW, bool RAW>
-__global__ __launch_bounds__(64 * NW, 8 / NW) void hamming_mfma_kernel(
+__global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
     const int32_t *__restrict__ q_off, const int32_t *__restrict__ q_cnt,
     const int32_t *__restrict__ t_off, const int32_t *__restrict__ t_cnt,
@@ -574,7 +574,7 @@ void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t
     return;                                                                                          \
   }
   SLAMHIP_MFMA_CASE(8, 1, 4) SLAMHIP_MFMA_CASE(8, 2, 4) SLAMHIP_MFMA_CASE(8, 2, 8)
-  SLAMHIP_MFMA_CASE(16, 1, 4) SLAMHIP_MFMA_CASE(16, 2, 4) SLAMHIP_MFMA_CASE(16, 2, 8)
+  SLAMHIP_MFMA_CASE(16, 1, 4) SLAMHIP_MFMA_CASE(16, 2, 4) SLAMHIP_MFMA_CASE(16, 2, 8) SLAMHIP_MFMA_CASE(16, 4, 4)
   SLAMHIP_MFMA_CASE(32, 1, 4)
 #undef SLAMHIP_MFMA_CASE
 }

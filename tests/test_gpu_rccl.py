@@ -130,13 +130,15 @@ def test_bench_multi_rank_path_runs_on_rccl_with_one_rank():
                MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5",
                         "--warmup", "2", "--preheat", "0.05", "--frames", "12", "--frontend-steps", "1",
-                        "--envelope-frames", "0", "--lc-keyframes", "6", "--no-sweep", "--no-cpu-baseline"],
+                        "--envelope-frames", "0", "--lc-keyframes", "6", "--sequence-frames", "31", "--no-sweep",
+                        "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     import json
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["frontend"]["value"] > 0 and line["loop_verify"]["value"] > 0
-    assert line["dist_backend"] == "nccl"
+    assert line["dist_backend"] == "nccl" and line["ranks_seen"] == 1
+    assert line["sequence_sharded"]["poses"] == 30
 
 
 def test_bench_starts_its_own_ranks():
@@ -148,7 +150,8 @@ def test_bench_starts_its_own_ranks():
     env.update(SLAMHIP_BENCH_BACKEND="gloo", SLAMHIP_BENCH_ONE_DEVICE="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5",
                         "--warmup", "2", "--preheat", "0.05", "--frames", "12", "--frontend-steps", "1",
-                        "--envelope-frames", "0", "--lc-keyframes", "6", "--no-sweep", "--no-cpu-baseline"],
+                        "--envelope-frames", "0", "--lc-keyframes", "6", "--sequence-frames", "31", "--no-sweep",
+                        "--no-cpu-baseline"],
                        capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     import json
@@ -160,6 +163,9 @@ def test_bench_starts_its_own_ranks():
     ho = line["frontend"]["hand_over"]
     assert ho["gather_ms"] > 0 and ho["pack_ms"] > 0 and ho["bytes_on_rank0"] >= 2 * ho["record_bytes_this_rank"] * 0.5
     assert line["loop_verify"]["value"] > 0
+    sq = line["sequence_sharded"]            # one 31-frame sequence cut in two: 30 poses come back merged
+    assert sq["frames"] == 31 and sq["poses"] == 30 and sq["pairs_on_rank0"] == 15 and sq["scaling"] == "strong"
+    assert sq["pose_error_vs_truth_max_m"] < 0.1
 
 
 def test_bench_launcher_returns_the_failing_ranks_code():
@@ -169,7 +175,8 @@ def test_bench_launcher_returns_the_failing_ranks_code():
     env.update(SLAMHIP_BENCH_BACKEND="gloo", SLAMHIP_BENCH_ONE_DEVICE="1", SLAMHIP_REHEARSE_FAIL_RANK="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_bench_failure.py"), "--gpus", "2",
                         "--steps", "5", "--warmup", "2", "--preheat", "0.05", "--frames", "4",
-                        "--frontend-steps", "1", "--envelope-frames", "0", "--lc-keyframes", "0", "--no-sweep",
+                        "--frontend-steps", "1", "--envelope-frames", "0", "--lc-keyframes", "0", "--sequence-frames", "0",
+                        "--no-sweep",
                         "--no-cpu-baseline", "--section-timeout", "20"],
                        capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert r.returncode != 0, (r.stdout[-1500:], r.stderr[-3000:])
@@ -182,7 +189,8 @@ def test_bench_reports_a_failed_section_with_a_nonzero_exit_code():
     env = dict(os.environ, SLAMHIP_REHEARSE_FAIL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_bench_failure.py"), "--gpus", "1",
                         "--steps", "5", "--warmup", "2", "--preheat", "0.05", "--frames", "4",
-                        "--frontend-steps", "1", "--envelope-frames", "0", "--lc-keyframes", "0", "--no-sweep",
+                        "--frontend-steps", "1", "--envelope-frames", "0", "--lc-keyframes", "0", "--sequence-frames", "0",
+                        "--no-sweep",
                         "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=env, cwd=ROOT)
     assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
     import json
