@@ -434,7 +434,7 @@ def bench_sequence(args, rank, world, dist, red_dev="cuda"):
         t = lap("gather", t)
         merged = None
         if rank == 0:
-            merged = sharding.merge_records([g.cpu().numpy() for g in got], F)
+            merged = sharding.merge_records(sharding.records_to_host(got, reuse_buffer=True), F)
             lap("to_host_and_merge", t)
         return merged
 
@@ -467,7 +467,7 @@ def bench_sequence(args, rank, world, dist, red_dev="cuda"):
                         "per rank with a halo frame; front-end, device-side record packing, one gather onto rank "
                         "0, copy to the host and merge into the per-frame arrays of the hand-over",
             "rank0_phase_seconds": {k: v / reps for k, v in phases.items()},
-            "record_bytes_total": int(sum(len(merged.f[k].reshape(-1).view(np.uint8)) for k in merged.f)),
+            "record_bytes_total": merged.nbytes,
             "poses": int(len(Rts)), "pose_error_vs_truth_max_m": err}
 
 

@@ -120,38 +120,88 @@ def pack_records(frames: Sequence[dict], pairs: Sequence[dict], first_frame: int
 
 
 class SequenceResult:
-    """Flat per-sequence arrays + offsets; frame(f) / pair(p) give views shaped
-    like what the reference builds per frame."""
+    """A whole sequence reassembled from per-rank records.  frame(f) / pair(p) give views shaped
+    like what the reference builds per frame; they index the owning rank's record where it lies
+    (no copy of the large per-row fields is made to merge the records).  `f` holds the flat
+    per-sequence arrays, concatenated on first use."""
 
-    def __init__(self, n_frames: int, desc_bytes: int, st_cnt, tm_cnt, fields: Dict[str, np.ndarray]):
+    def __init__(self, n_frames: int, desc_bytes: int, parts):
+        """parts: parsed records (first_frame, first_pair, desc_bytes, st_cnt, tm_cnt, fields),
+        those with frames sorted by first_frame and covering [0, n_frames) without gaps."""
         self.n_frames, self.desc_bytes = n_frames, desc_bytes
         self.frame_cross_check = False        # set by run_sharded; selects the hand-over shape (db_adapter)
-        self.st_cnt, self.tm_cnt, self.f = st_cnt, tm_cnt, fields
-        self.st_off = np.concatenate([[0], np.cumsum(st_cnt)]).astype(np.int64)
-        self.tm_off = np.concatenate([[0], np.cumsum(tm_cnt)]).astype(np.int64)
+        self._parts = list(parts)
+        self._by_frame = [p for p in parts if len(p[3])]
+        self._by_pair = sorted((p for p in parts if len(p[4])), key=lambda p: p[1])
+        self._frame_first = np.array([p[0] for p in self._by_frame], dtype=np.int64)
+        self._pair_first = np.array([p[1] for p in self._by_pair], dtype=np.int64)
+        self._frame_off = [np.concatenate([[0], np.cumsum(p[3])]).astype(np.int64) for p in self._by_frame]
+        self._pair_off = [np.concatenate([[0], np.cumsum(p[4])]).astype(np.int64) for p in self._by_pair]
+        z = np.zeros(0, np.int64)
+        self.st_cnt = np.concatenate([p[3] for p in self._by_frame]) if self._by_frame else z
+        self.tm_cnt = np.concatenate([p[4] for p in self._by_pair]) if self._by_pair else z
+        self.st_off = np.concatenate([[0], np.cumsum(self.st_cnt)]).astype(np.int64)
+        self.tm_off = np.concatenate([[0], np.cumsum(self.tm_cnt)]).astype(np.int64)
+        self._Rt = (np.concatenate([p[5]["Rt"] for p in self._by_pair]).reshape(-1, 3, 4) if self._by_pair
+                    else np.zeros((0, 3, 4)))
+        self._flat = None
+
+    def _locate(self, firsts, i):
+        k = int(np.searchsorted(firsts, i, side="right")) - 1
+        return k, i - int(firsts[k])
 
     def frame(self, f: int) -> dict:
-        sl = slice(int(self.st_off[f]), int(self.st_off[f + 1]))
-        out = {name: self.f[name][sl] for name, _, _ in FRAME_FIELDS}
+        k, j = self._locate(self._frame_first, f)
+        fields, off = self._by_frame[k][5], self._frame_off[k]
+        sl = slice(int(off[j]), int(off[j + 1]))
+        out = {name: fields[name][sl] for name, _, _ in FRAME_FIELDS}
         pl, pr = out["pix_left"], out["pix_right"]
         out["links"] = np.column_stack([pl[:, 0].astype(np.float64), pr[:, 0].astype(np.float64),
                                         (pl[:, 1].astype(np.float64) + pr[:, 1].astype(np.float64)) / 2])
         return out
 
     def pair(self, p: int) -> dict:
-        sl = slice(int(self.tm_off[p]), int(self.tm_off[p + 1]))
-        info = self.f["info"][p]
-        return {"query_idx": self.f["tm_query_idx"][sl], "train_idx": self.f["tm_train_idx"][sl],
-                "dist": self.f["tm_dist"][sl], "mask": self.f["tm_mask"][sl].astype(bool),
-                "Rt": self.f["Rt"][p], "Rt_ransac": self.f["Rt_ransac"][p],
+        k, j = self._locate(self._pair_first, p)
+        fields, off = self._by_pair[k][5], self._pair_off[k]
+        sl = slice(int(off[j]), int(off[j + 1]))
+        info = fields["info"][j]
+        return {"query_idx": fields["tm_query_idx"][sl], "train_idx": fields["tm_train_idx"][sl],
+                "dist": fields["tm_dist"][sl], "mask": fields["tm_mask"][sl].astype(bool),
+                "Rt": fields["Rt"][j].reshape(3, 4), "Rt_ransac": fields["Rt_ransac"][j].reshape(3, 4),
                 "best_index": int(info[0]), "best_count": int(info[1]), "iterations": int(info[2]),
                 "n_iter_required": int(info[3]), "domain_error": bool(info[4]),
-                "n_matches": int(self.tm_cnt[p])}
+                "n_matches": int(off[j + 1] - off[j])}
+
+    @property
+    def f(self) -> Dict[str, np.ndarray]:
+        """Flat per-sequence arrays (every field over all frames / pairs), built on first use."""
+        if self._flat is None:
+            D = self.desc_bytes
+            out = {}
+            for name, dt, w in FRAME_FIELDS:
+                cols = D if w < 0 else w
+                arrs = [p[5][name] for p in self._by_frame]
+                out[name] = np.concatenate(arrs) if arrs else np.zeros((0, cols) if cols > 1 or w < 0 else 0, dt)
+            for name, dt, w in PAIR_ROW_FIELDS:
+                arrs = [p[5]["tm_" + name] for p in self._by_pair]
+                out["tm_" + name] = np.concatenate(arrs) if arrs else np.zeros(0, dt)
+            for name, dt, w in PAIR_FIXED_FIELDS:
+                arrs = [p[5][name] for p in self._by_pair]
+                out[name] = np.concatenate(arrs) if arrs else np.zeros((0, w), dt)
+            out["Rt"] = out["Rt"].reshape(-1, 3, 4)
+            out["Rt_ransac"] = out["Rt_ransac"].reshape(-1, 3, 4)
+            self._flat = out
+        return self._flat
+
+    @property
+    def nbytes(self) -> int:
+        """Bytes of all fields of all records."""
+        return int(sum(a.nbytes for p in self._parts for a in p[5].values()))
 
     @property
     def relative_Rts(self) -> np.ndarray:
         """(n_frames-1,3,4): the array the reference pickles as `relative_Rts`."""
-        return self.f["Rt"]
+        return self._Rt
 
     @property
     def frames(self):
@@ -212,22 +262,37 @@ def merge_records(blobs: Sequence[np.ndarray], n_frames: int) -> SequenceResult:
     if nf != n_frames or npairs != max(n_frames - 1, 0):
         raise RuntimeError(f"gathered {nf} frames / {npairs} pairs, expected {n_frames} / {n_frames - 1}")
     D = parsed[0][2] if parsed else 0
-    fields = {}
-    for name, dt, w in FRAME_FIELDS:
-        cols = D if w < 0 else w
-        arrs = [p[5][name] for p in by_frame]
-        fields[name] = np.concatenate(arrs) if arrs else np.zeros((0, cols) if cols > 1 or w < 0 else 0, dt)
-    for name, dt, w in PAIR_ROW_FIELDS:
-        arrs = [p[5]["tm_" + name] for p in by_pair]
-        fields["tm_" + name] = np.concatenate(arrs) if arrs else np.zeros(0, dt)
-    for name, dt, w in PAIR_FIXED_FIELDS:
-        arrs = [p[5][name] for p in by_pair]
-        fields[name] = np.concatenate(arrs) if arrs else np.zeros((0, w), dt)
-    fields["Rt"] = fields["Rt"].reshape(-1, 3, 4)
-    fields["Rt_ransac"] = fields["Rt_ransac"].reshape(-1, 3, 4)
-    st_cnt = np.concatenate([p[3] for p in by_frame]) if by_frame else np.zeros(0, np.int64)
-    tm_cnt = np.concatenate([p[4] for p in by_pair]) if by_pair else np.zeros(0, np.int64)
-    return SequenceResult(n_frames, D, st_cnt, tm_cnt, fields)
+    return SequenceResult(n_frames, D, by_frame + [p for p in by_pair if not len(p[3])])
+
+
+def records_to_host(blobs: Sequence[torch.Tensor], reuse_buffer: bool = False) -> List[np.ndarray]:
+    """Device records -> NumPy arrays through one page-locked buffer (several times the rate of
+    pageable copies), one synchronisation for all of them.  The arrays are views of that buffer
+    and keep it alive.  `reuse_buffer`: take the module's buffer, kept and grown on demand
+    (allocating page-locked memory costs more than the copy), instead of a new one -- the arrays
+    of the previous call with this option are overwritten then."""
+    global _host_stage
+    sizes = [int(b.numel()) for b in blobs]
+    offs = np.concatenate([[0], np.cumsum([(n + 63) // 64 * 64 for n in sizes])]).astype(np.int64)
+    total = max(int(offs[-1]), 1)
+    pin = torch.cuda.is_available()
+    if not reuse_buffer:
+        stage = torch.empty(total, dtype=torch.uint8, pin_memory=pin)
+    else:
+        if _host_stage is None or _host_stage.numel() < total:
+            _host_stage = torch.empty(int(total * 1.25), dtype=torch.uint8, pin_memory=pin)
+        stage = _host_stage
+    out = []
+    for b, o, n in zip(blobs, offs[:-1], sizes):
+        dst = stage[int(o):int(o) + n]
+        dst.copy_(b.reshape(-1), non_blocking=True)
+        out.append(dst.numpy())
+    if torch.cuda.is_available():
+        torch.cuda.current_stream().synchronize()
+    return out
+
+
+_host_stage = None
 
 
 def all_gather_records(blob, group=None) -> List[np.ndarray]:
@@ -280,11 +345,12 @@ def gather_records(blob: torch.Tensor, dst: int = 0, group=None) -> Optional[Lis
 
 def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
                 samples: Optional[np.ndarray] = None, dst: int = 0,
-                force_collective: bool = False) -> Optional[SequenceResult]:
+                force_collective: bool = False, reuse_host_buffer: bool = False) -> Optional[SequenceResult]:
     """Process this rank's share of `frames` on its GPU and gather the records
     on rank `dst`, which returns the merged result (other ranks return None).
     With one rank the record is parsed directly; `force_collective` sends it
-    through the gather all the same (needs an initialised process group)."""
+    through the gather all the same (needs an initialised process group).
+    `reuse_host_buffer`: see records_to_host (the previous result's arrays are overwritten)."""
     n_frames = len(frames)
     lo, hi, (plo, phi), (flo, fhi) = frames_for_rank(n_frames, world, rank)
     desc_bytes = int(np.asarray(frames[0][2]).shape[1])
@@ -295,11 +361,11 @@ def run_sharded(frontend, frames: Sequence, rank: int, world: int, group=None,
     else:
         blob = torch.from_numpy(pack_records([], [], 0, 0, desc_bytes))
     if world == 1 and not force_collective:
-        merged = merge_records([blob.cpu().numpy()], n_frames)
+        merged = merge_records(records_to_host([blob], reuse_host_buffer), n_frames)
     else:
         got = gather_records(blob, dst, group)
         if got is None:
             return None
-        merged = merge_records([g.cpu().numpy() for g in got], n_frames)
+        merged = merge_records(records_to_host(got, reuse_host_buffer), n_frames)
     merged.frame_cross_check = bool(getattr(frontend, "frame_cross_check", False))   # for the hand-over
     return merged
