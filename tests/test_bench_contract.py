@@ -7,7 +7,7 @@ import os
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LINE = os.path.join(ROOT, "profiles", "r2", "bench.json")
+LINE = os.path.join(ROOT, "profiles", "r3", "bench.json")
 
 
 @pytest.fixture(scope="module")

@@ -14,10 +14,13 @@ stats() {   # stats NAME -- command...
   find $OUT/prof_tmp -name "*kernel_stats.csv" -exec cp {} $OUT/${name}_kernel_stats_${TAG}.csv \;
   rm -rf $OUT/prof_tmp
 }
-MARGS="--no-cpu-baseline --frames 0 --lc-keyframes 0 --no-sweep"
+MARGS="--no-cpu-baseline --frames 0 --lc-keyframes 0 --sequence-frames 0 --no-sweep"
 stats bench_matcher8k -- python3 bench.py --steps 400 --warmup 20 $MARGS
 SLAMHIP_MATCHER=popcount stats bench_matcher8k_popcount -- python3 bench.py --steps 400 --warmup 20 $MARGS
 stats frontend500 -- python3 tools/profile_frontend.py 500 1500
+SLAMHIP_PROFILE_SHAPE=readme stats frontend500_readme -- python3 tools/profile_frontend.py 500 1500
+SLAMHIP_PROFILE_VARIANT=9 stats frontend500_one_group_per_wave -- python3 tools/profile_frontend.py 500 1500
+stats online_pair -- python3 tools/profile_online.py 1500
 stats frontend_envelope60 -- python3 tools/profile_frontend.py 60 2000 8000
 stats loop_verify270 -- python3 tools/profile_loop_verify.py 270
 stats l2_8k -- python3 tools/profile_l2.py 8192 256 10
@@ -32,5 +35,6 @@ done
 rm -rf $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/pmc_SQ_INSTS_VALU $OUT/pmc_SQ_INSTS_MFMA $OUT/prof_tmp.err
 [ -x tools/mfma_mix_probe ] && timeout -k 10 60 tools/mfma_mix_probe > $OUT/mfma_mix_probe_${TAG}.log 2>&1
 [ -x tools/bench_call ] && timeout -k 10 120 tools/bench_call 61 > $OUT/bench_call_${TAG}.log 2>&1
+timeout -k 10 120 python3 tools/try_variants.py 8192 > $OUT/matcher_variants_${TAG}.log 2>&1
 timeout -k 10 600 python3 -u -m pytest tests -m gpu -q --timeout 120 --timeout-method thread > $OUT/pytest_gpu_${TAG}.log 2>&1
 timeout -k 10 280 python3 bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err
