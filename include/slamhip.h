@@ -77,8 +77,9 @@ const char *slamhip_strerror(int code);
  * cost; slamhip_profile_end then reports the time of all of them), knob 11 = batched launches
  * of the matrix-core matcher (64 pairs or more) deal their blocks to the chip's eight XCDs pair
  * by pair, so that a pair's rows come into one L2 (1, the default), or use the plain grid (0);
- * same results.  Process-global; not
- * for use while other threads are inside the library. */
+ * same results; knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
+ * per SIMD (64-byte rows only; measured slower).  Process-global; not for use while other threads
+ * are inside the library. */
 int slamhip_tune(int knob, int value);
 
 /* Which kernel family the Hamming matcher uses when knob 0 forces nothing:
