@@ -62,7 +62,7 @@ const char *slamhip_strerror(int code);
  * the counts are identical in all four), knob 3 = matcher block size (0 auto, 256 or
  * 128 queries per block), knob 4 = pair RANSAC launch scheme (0 auto: calls with at
  * most 64 pairs solve and count every hypothesis in one pass, longer front-end calls run
- * three rounds of 256 hypotheses and the rest of the cap as one merged launch; 1 always
+ * two rounds of 256 hypotheses (knob 13) and the rest of the cap as one merged launch; 1 always
  * rounds of 256; 2 rounds with the merged tail whatever the pair count; identical results;
  * set it before sizing a workspace), knob 5 = sort
  * algorithm (0 auto: radix passes in LDS where the segments fit, 1 rank counting, 2 bitonic
@@ -77,7 +77,9 @@ const char *slamhip_strerror(int code);
  * cost; slamhip_profile_end then reports the time of all of them), knob 11 = batched launches
  * of the matrix-core matcher (64 pairs or more) deal their blocks to the chip's eight XCDs pair
  * by pair, so that a pair's rows come into one L2 (1, the default), or use the plain grid (0);
- * same results; knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
+ * same results; knob 13 = rounds of 256 hypotheses a long front-end call runs over all its pairs
+ * before the rest of the iteration cap goes through the merged launch (1..3, default 2; set it before
+ * sizing a workspace; identical results); knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
  * per SIMD (64-byte rows only; measured slower).  Process-global; not for use while other threads
  * are inside the library. */
 int slamhip_tune(int knob, int value);

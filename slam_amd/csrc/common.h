@@ -46,6 +46,12 @@ extern int g_ransac_mode;
 // 1 (default): batched matrix-core matcher launches deal their blocks to the XCDs pair by pair;
 // 0: plain three-dimensional grid.  Set through slamhip_tune(11, value).
 extern int g_xcd_remap;
+// Rounds of 256 hypotheses a long front-end call runs as launch pairs over all pairs before
+// the rest of the iteration cap goes through the merged tail (1..3, default 2: a third round finds
+// next to nothing to do on typical data and still dispatches its whole grid; measured 1-3 % of a
+// pass on five workloads).  Same results.  Set through slamhip_tune(13, value), before a workspace
+// is sized.
+extern int g_wide_rounds;
 
 // splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,

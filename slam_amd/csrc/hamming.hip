@@ -1011,6 +1011,7 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 7) g_mfma_rows_per_split = value > 0 ? value : 4096;
   else if (knob == 9) g_raw_rows = value ? 1 : 0;
   else if (knob == 11) slamhip_internal::g_xcd_remap = value ? 1 : 0;
+  else if (knob == 13) slamhip_internal::g_wide_rounds = (value >= 1 && value <= 3) ? value : 2;
   else if (knob == 10) g_prof_repeat = value >= 1 && value <= 64 ? value : 1;
   else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
   else return SLAMHIP_EINVAL;

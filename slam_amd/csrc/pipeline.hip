@@ -654,7 +654,12 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
 // thousands.
 // MODE: 0 = fp64 only, 1 = packed-fp32 screen, 2 = the same for a rectified pair, 3 = as 2 for pairs
 // that are mostly unrelated (count_chunk_inliers_sparse; needs the solve launch's hyp32 table).
-constexpr int kWideRounds = 3;
+constexpr int kWideRounds = 3;   // rounds whose counting launch has one block per chunk (calls without a merged tail)
+// Rounds of a front-end call before its merged tail (slamhip_internal::g_wide_rounds, 1..3).
+static int wide_rounds() {
+  const int w = slamhip_internal::g_wide_rounds;
+  return w < 1 ? 1 : (w > kWideRounds ? kWideRounds : w);
+}
 // One wavefront's share: hypotheses [64 * hyp_group, +64) of table row `row` (a block of
 // pair p's hypotheses) against the pair's correspondences [span0, span0 + span_len).
 template <int MODE>
@@ -921,7 +926,7 @@ int single_pass_slots(int n_pairs, int n_iter_max) {
   return slots;
 }
 
-// The rounds after the first kWideRounds reach few pairs (those with a small consensus set):
+// The rounds after the first wide_rounds() reach few pairs (those with a small consensus set):
 // each would be two launches that find nearly nothing to do.  With `merge_tail` they run as ONE
 // multi-slot launch pair without replays in between (as the single pass does), behind a launch
 // that only replays the last wide round; the finishing launch replays the tail's blocks in
@@ -929,7 +934,7 @@ int single_pass_slots(int n_pairs, int n_iter_max) {
 // per (pair, tail block).
 int tail_slots(int n_iter_max, bool merge_tail) {
   const int rounds = slamhip_ceil_div(n_iter_max > 0 ? n_iter_max : 1, kHypPerRound);
-  return (merge_tail && rounds >= kWideRounds + 2) ? rounds - kWideRounds : 0;
+  return (merge_tail && rounds >= wide_rounds() + 2) ? rounds - wide_rounds() : 0;
 }
 
 // Where the tables of a call lie in its workspace: pose / count / fp32-image tables of
@@ -981,7 +986,8 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
   double *rt_tail = (double *)((uintptr_t)ws + T.rt_tail);
   int32_t *counts_tail = (int32_t *)((uintptr_t)ws + T.counts_tail);
   int32_t *list = (int32_t *)((uintptr_t)ws + T.list);
-  const int rounds = slots > 1 ? 1 : (tail ? kWideRounds : slamhip_ceil_div(prm.n_iter_max, kHypPerRound));
+  const int wide = wide_rounds();
+  const int rounds = slots > 1 ? 1 : (tail ? wide : slamhip_ceil_div(prm.n_iter_max, kHypPerRound));
   const int chunks = slamhip_ceil_div(max_points > 0 ? max_points : 1, kPtsPerChunk);
   const long long pair0 = prm.pair0;
   const int mode = screening_mode(slamhip_internal::g_ransac_screen, prm.cam.K, prm.cam.MR, prm.thresh);
@@ -1016,11 +1022,11 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
     }
     if (tail) {
       // replay of the last wide round (state and winner pose up to date), then every block left
-      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, 1), dim3(kBlock), 0, st, kWideRounds, 1, 1, 0,
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, 1), dim3(kBlock), 0, st, wide, 1, 1, 0,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr,
                          (const float *)nullptr);
-      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, tail), dim3(kBlock), 0, st, kWideRounds, tail, 0, 1,
+      hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, tail), dim3(kBlock), 0, st, wide, tail, 0, 1,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt_tail, counts_tail,
                          pose_ransac + 12 * (size_t)g0, info + 8 * (size_t)g0, list, (float *)nullptr,
                          (const float *)nullptr);
@@ -1030,7 +1036,7 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       hipLaunchKernelGGL(count_list, dim3((unsigned)(most < kTailGrid ? most : kTailGrid)), dim3(64), 0, st,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt_tail, counts_tail,
                          info + 8 * (size_t)g0, chunks, tail, (const float *)nullptr, np, (const int32_t *)list);
-      hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, kWideRounds, tail,
+      hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, wide, tail,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt_tail, counts_tail,
                          pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
     } else {

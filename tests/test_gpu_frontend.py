@@ -662,3 +662,35 @@ def test_fused_sort_launches_equal_the_separate_ones(cross):
             assert x.keys() == y.keys()
             for k in x:
                 np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+
+
+def test_any_number_of_rounds_before_the_merged_tail_gives_the_same_results():
+    """A long front-end call runs 1, 2 (the default) or 3 rounds of 256 hypotheses over all pairs
+    before the rest of the iteration cap goes through the merged launch (tune knob 13): the same
+    samples are replayed in the same order, so every output is identical -- with pairs that stop
+    in the first round, in the tail, and at the cap."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    keys = ("ransac_info", "pose_ransac", "pose_refined", "tm_mask")
+    try:
+        for kw, n_iter in ((dict(clutter=0.63, landmark_density=0.58), 2500), (dict(clutter=0.6, landmark_density=1.7), 1100),
+                           (dict(clutter=0.5), 700)):
+            seq = StereoSequence(cam, n_frames=70, n_features=(300, 1000), seed=17, **kw)
+            frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(70))]
+            ref = None
+            for knob in (3, 2, 1):
+                assert _lib.lib.slamhip_tune(13, knob) == 0
+                h = TrackingFrontend(cam, n_iter_max=n_iter, seed=9).run(frames).to_host()   # its own workspace
+                got = {k: h[k].copy() for k in keys}
+                ref = ref or got
+                for k in keys:
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{kw}, {knob} rounds: {k}")
+            it = ref["ransac_info"].reshape(-1, 8)[:69, 2]
+            if n_iter == 1100:
+                assert it.max() > 768, it.max()          # pairs that run into the tail and to the cap
+            if n_iter == 2500:
+                assert it.min() < 256 < it.max(), (it.min(), it.max())   # first round and beyond
+    finally:
+        _lib.lib.slamhip_tune(13, 2)
