@@ -498,7 +498,8 @@ struct RansacParams {
 // replay updates the pair's state); `generate`: sample and solve (a launch with replay
 // alone brings the state up to date for a multi-slot launch that follows).
 // Pose table layout: rt[((pair * slots + slot) * 12 + element) * kHypPerRound + lane].
-// `list` (may be null): list[0] counts, and list[1..] names, the table rows this launch
+// `list` (may be null): list[0] counts, list[1] holds the largest correspondence count among, and
+// list[2..] names, the table rows this launch
 // generated hypotheses for; a launch with `generate` off clears the count instead.
 // `hyp32` (may be null): per valid hypothesis the fp32 image of its projection matrices and
 // its error-bound constants (Hyp32), hyp32[(row * kHyp32Floats + field) * kHypPerRound + lane].
@@ -552,7 +553,7 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
     else if (sh[1] >= 0)
       pose_ransac[12 * (size_t)p + threadIdx.x] = rt[(row * 12 + threadIdx.x) * kHypPerRound + sh[1]];
   }
-  if (list != nullptr && !generate && p == 0 && threadIdx.x == 0) list[0] = 0;   // the next launch appends
+  if (list != nullptr && !generate && p == 0 && threadIdx.x == 0) { list[0] = 0; list[1] = 0; }   // the next launch appends
   if (sh[0] || !generate) return;
   __syncthreads();  // the winner has been read before its slot is overwritten
 
@@ -560,8 +561,10 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
   // current requirement can never be consumed by the replay: it is not generated.
   const int it = (first_block + slot) * kHypPerRound + (int)threadIdx.x;
   const bool active = it < prm.n_iter_max && it < sh[2];
-  if (list != nullptr && threadIdx.x == 0 && active)      // lane 0 holds the block's first hypothesis
-    list[1 + atomicAdd(&list[0], 1)] = (int32_t)row;
+  if (list != nullptr && threadIdx.x == 0 && active) {    // lane 0 holds the block's first hypothesis
+    list[2 + atomicAdd(&list[0], 1)] = (int32_t)row;
+    atomicMax(&list[1], n);
+  }
   bool valid = false;
   int own = 0;   // inliers among the staged pairs of the hypothesis' own sample points (cpr_own)
   if (active) {
@@ -801,11 +804,13 @@ __device__ __forceinline__ void ransac_count_list_body(
     const int32_t *__restrict__ list) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   constexpr int kGroups = kHypPerRound / 64;
+  // chunks any listed pair has correspondences for (the host's `chunks` comes from its row bound)
+  chunks = min(chunks, (list[1] + kPtsPerChunk - 1) / kPtsPerChunk);
   const long long n_items = (long long)list[0] * kGroups * chunks;
   for (long long w = blockIdx.x; w < n_items; w += gridDim.x) {
     const int chunk = (int)(w % chunks);
     const int hyp_group = (int)((w / chunks) % kGroups);
-    const int row = list[1 + w / ((long long)chunks * kGroups)];
+    const int row = list[2 + w / ((long long)chunks * kGroups)];
     ransac_count_item<MODE>(lds, row / slots, (size_t)row, hyp_group, chunk * kPtsPerChunk, kPtsPerChunk,
                             obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, hyp32);
     __syncthreads();   // the staged chunk has been read by every lane before the next item's overwrites it
@@ -954,7 +959,7 @@ RansacTables ransac_tables(size_t rows, size_t tail_rows) {
   t.hyp32 = take(rows * kHyp32Floats * kHypPerRound * sizeof(float));
   t.rt_tail = take(tail_rows * 12 * kHypPerRound * sizeof(double));
   t.counts_tail = take(tail_rows * kHypPerRound * sizeof(int32_t));
-  t.list = take((tail_rows + 1) * sizeof(int32_t));
+  t.list = take((tail_rows + 2) * sizeof(int32_t));
   t.total = o;
   return t;
 }
