@@ -54,10 +54,18 @@ __device__ __forceinline__ double wave_sum(double v) {
 // exp of a rotation vector (Rodrigues), row-major 3x3
 __device__ void so3_exp(const double *w, double *R) {
   const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
-  const double th = sqrt(th2);
+  const double th = sqrt(th2);   // used by the large-angle branch only
   double a, b;  // sin(th)/th, (1-cos(th))/th^2
-  if (th < 1e-8) { a = 1.0 - th2 / 6.0; b = 0.5 - th2 / 24.0; }
-  else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
+  if (th2 < 0.0625) {
+    // |w| < 0.25 rad (every step from a RANSAC-grade start): the two series to th^18 / th^20, whose first
+    // dropped terms are below 1e-26 there -- a dozen multiply-adds in place of fp64 sin and cos with their
+    // range reduction, in the one lane whose chain every pass of the kernel waits for
+    const double x = th2;
+    a = 1.0 + x * (-1.0 / 6 + x * (1.0 / 120 + x * (-1.0 / 5040 + x * (1.0 / 362880 + x * (-1.0 / 39916800 +
+        x * (1.0 / 6227020800.0 + x * (-1.0 / 1307674368000.0 + x * (1.0 / 355687428096000.0))))))));
+    b = 0.5 + x * (-1.0 / 24 + x * (1.0 / 720 + x * (-1.0 / 40320 + x * (1.0 / 3628800 + x * (-1.0 / 479001600 +
+        x * (1.0 / 87178291200.0 + x * (-1.0 / 20922789888000.0 + x * (1.0 / 6402373705728000.0))))))));
+  } else { a = sin(th) / th; b = (1.0 - cos(th)) / th2; }
   const double wx = w[0], wy = w[1], wz = w[2];
   R[0] = 1.0 - b * (wy * wy + wz * wz); R[1] = -a * wz + b * wx * wy; R[2] = a * wy + b * wx * wz;
   R[3] = a * wz + b * wx * wy; R[4] = 1.0 - b * (wx * wx + wz * wz); R[5] = -a * wx + b * wy * wz;
@@ -153,8 +161,10 @@ __device__ void accumulate(const PT *__restrict__ pts, const float *__restrict__
     if (lane == 0) lds[wave * 28 + i] = s;
   }
   __syncthreads();
-  if (threadIdx.x == 0)
-    for (int i = 0; i < 28; ++i) out[i] = lds[i] + lds[28 + i] + lds[56 + i] + lds[84 + i];
+  if (threadIdx.x < 28) {
+    const int i = threadIdx.x;
+    out[i] = (lds[i] + lds[28 + i]) + (lds[56 + i] + lds[84 + i]);
+  }
   __syncthreads();
 }
 
@@ -215,6 +225,10 @@ __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
       // Convergence is quadratic near the minimum: a step below 1e-10 (rad, m) means
       // the pose already sits at it to that accuracy, so the pass that would only
       // confirm it is not spent.
+      // A step below 1e-7 from an undamped system (no rejection behind it) is a Gauss-Newton step
+      // next to the minimum: the pose it leads to is at the minimum to ~step^2, far inside what a
+      // pass that only confirmed it could tell, so it is taken as it is and that pass is not spent.
+      const bool last = ok && step >= 1e-10 && step < 1e-7 && lambda <= 1e-5;
       if (!ok || step < 1e-10) {
         ctrl[0] = 0;
       } else {
@@ -226,6 +240,11 @@ __global__ __launch_bounds__(kRefThreads) void refine_pose_kernel(
           cand[4 * i + 3] += dx[3 + i];
         }
         ctrl[0] = 1;
+        if (last) {
+          for (int i = 0; i < 12; ++i) pose[i] = cand[i];
+          ctrl[0] = 0;
+          ++iters;
+        }
       }
     }
     __syncthreads();
