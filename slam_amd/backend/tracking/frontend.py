@@ -336,8 +336,9 @@ class TrackingFrontend:
         dev = inp.kp_left.device
         i32 = lambda n: torch.empty(max(n, 1), dtype=torch.int32, device=dev)
         f32 = lambda n: torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        # the outputs that must start at zero share one allocation (one fill launch
-        # instead of five: the one-pair online call is bounded by its launches)
+        # The pair outputs share one allocation.  A call with at least one pair writes every
+        # element of them (the mask rows of a frame beyond its matches included), so nothing is
+        # filled beforehand; a call of one frame has no pair, and they read as zero.
         P = max(F - 1, 1)
         zsizes = (("pose_ransac", torch.float64, P * 12),
                   ("pose_refined", torch.float64, P * 12), ("ransac_info", torch.int32, P * 8),
@@ -346,7 +347,7 @@ class TrackingFrontend:
         for _, dt, n in zsizes:
             offs.append(total)
             total = (total + n * torch.empty(0, dtype=dt).element_size() + 15) // 16 * 16
-        zbuf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        zbuf = (torch.empty if F >= 2 and NL > 0 else torch.zeros)(total, dtype=torch.uint8, device=dev)
         t = {
             "st_count": i32(F), "st_left": i32(NL), "st_right": i32(NL), "st_dist": i32(NL),
             "st_xyz": f32(NL * 3), "st_pix_left": f32(NL * 2), "st_pix_right": f32(NL * 2),

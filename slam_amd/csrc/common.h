@@ -52,6 +52,14 @@ extern int g_xcd_remap;
 // pass on five workloads).  Same results.  Set through slamhip_tune(13, value), before a workspace
 // is sized.
 extern int g_wide_rounds;
+// Front-end calls of a few frames (frame-at-a-time use): 1 (default) = their stages run as fused
+// launches (matcher splits folded by the stage behind the matcher, sort + filter + triangulation in
+// one launch per stage, refinement behind the RANSAC replay); 0 = the launches of a long call.
+// Same results.  Set through slamhip_tune(14, value).
+extern int g_small_call_fusion;
+// Correspondences per one-wavefront block of the consensus count of such calls (0 = chosen from
+// the sizes).  Set through slamhip_tune(15, value).
+extern int g_small_call_span;
 
 // splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
@@ -70,13 +78,22 @@ int knn2_plan_splits(int n_pairs, int max_nq, int max_nt, int desc_bytes);
 // d_out_off != NULL: the result of query row r of pair p is written at output row
 // d_out_off[p] + r of idx2/dist2, which then hold n_out_total rows (the same
 // query set may take part in many pairs).
+// `unfolded` (may be null): the caller's next kernel folds the train splits itself.  A call that
+// ran with more than one split then leaves out its merge launch and reports where the per-split
+// results lie: part[split * rows + output row] = (smallest, second smallest) key of the split,
+// key = distance << 21 | train row within the pair, 0xFFFFFFFF = none; idx2 / dist2 are not
+// written.  With splits == 1 the results are in idx2 / dist2 as usual.
+struct Knn2Splits {
+  const uint2 *part;
+  int splits, rows;
+};
 int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_total, int desc_bytes,
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
          hipStream_t st, const int32_t *d_out_off = nullptr, int n_out_total = -1,
          bool best_only = false,    // best_only: second-best entries come back as -1
-         int splits = 0);
+         int splits = 0, Knn2Splits *unfolded = nullptr);
 // Matrix-core matcher (hamming_mfma.hip): same arguments as the popcount kernel's launch.
 // W = packed dwords per row, G = groups of 32 queries per wave (1 or 2; 32-word rows: 1),
 // NW = waves per block (4, or 8 with G = 2 and rows of at most 16 words).

@@ -1,5 +1,6 @@
-// Device code shared by the triangulation kernels: one-sided (Hestenes) Jacobi
-// solve of the 4x4 DLT system, one problem per lane, fp64.
+// Device code shared by the triangulation kernels: the null vector of the 4x4 DLT system, one
+// problem per lane, fp64 -- by inverse iteration where that settles (every match that has
+// passed the stereo filter), by one-sided (Hestenes) Jacobi sweeps otherwise.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -48,8 +49,61 @@ __device__ __forceinline__ bool jacobi_pair(double (&a)[4][4], double (&v)[4][4]
   return true;
 }
 
+// The same vector by inverse iteration on B = A^T A (x <- B^-1 x, normalised): the error shrinks by
+// (s4 / s3)^2 per step, and a match that has passed the row filter has s3 / s4 of some hundred (its two
+// rays nearly meet), so three or four steps of two triangular solves reach what a step can no longer
+// change -- a few hundred instructions where the Jacobi sweeps below take some two thousand.  B is
+// factored once (Cholesky with the pivots' reciprocal roots kept; a pivot that rounding has pushed to
+// zero or below, as for rays that meet exactly, is lifted to 2^-60 trace(B): a perturbation of B below
+// its own rounding, and inverse iteration does not mind a nearly singular factor -- it is what singles
+// the vector out).  Forming B squares the condition number, but the vector's error is eps s1^2 / s3^2
+// (s1 / s3 is about 5 for stereo geometry), not eps s1^2 / s4^2.  Returns false when the steps have not
+// settled (s4 close to s3: no well-defined answer, or a matrix of zeros); the caller then takes the sweeps.
+constexpr int kInverseIterations = 16;
+__device__ __forceinline__ bool null_vector_by_inverse_iteration(const double (&a)[4][4], double (&x)[4]) {
+  double b00 = 0.0, b01 = 0.0, b02 = 0.0, b03 = 0.0, b11 = 0.0, b12 = 0.0, b13 = 0.0, b22 = 0.0, b23 = 0.0,
+         b33 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    b00 = fma(a[i][0], a[i][0], b00); b01 = fma(a[i][0], a[i][1], b01); b02 = fma(a[i][0], a[i][2], b02);
+    b03 = fma(a[i][0], a[i][3], b03); b11 = fma(a[i][1], a[i][1], b11); b12 = fma(a[i][1], a[i][2], b12);
+    b13 = fma(a[i][1], a[i][3], b13); b22 = fma(a[i][2], a[i][2], b22); b23 = fma(a[i][2], a[i][3], b23);
+    b33 = fma(a[i][3], a[i][3], b33);
+  }
+  const double lift = ((b00 + b11) + (b22 + b33)) * 8.673617379884035e-19;   // 2^-60 trace
+  const double i0 = rsqrt(fmax(b00, lift));
+  const double l10 = b01 * i0, l20 = b02 * i0, l30 = b03 * i0;
+  const double i1 = rsqrt(fmax(fma(-l10, l10, b11), lift));
+  const double l21 = fma(-l20, l10, b12) * i1, l31 = fma(-l30, l10, b13) * i1;
+  const double i2 = rsqrt(fmax(fma(-l21, l21, fma(-l20, l20, b22)), lift));
+  const double l32 = fma(-l31, l21, fma(-l30, l20, b23)) * i2;
+  const double i3 = rsqrt(fmax(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, b33))), lift));
+  // start: a point on the optical axis in front of the cameras, (0, 0, 3/4, 1) normalised
+  double x0 = 0.0, x1 = 0.0, x2 = 0.6, x3 = 0.8;
+  bool settled = false;
+  for (int it = 0; it < kInverseIterations && !settled; ++it) {
+    const double z0 = x0 * i0;
+    const double z1 = fma(-l10, z0, x1) * i1;
+    const double z2 = fma(-l21, z1, fma(-l20, z0, x2)) * i2;
+    const double z3 = fma(-l32, z2, fma(-l31, z1, fma(-l30, z0, x3))) * i3;
+    double y3 = z3 * i3;
+    double y2 = fma(-l32, y3, z2) * i2;
+    double y1 = fma(-l31, y3, fma(-l21, y2, z1)) * i1;
+    double y0 = fma(-l30, y3, fma(-l20, y2, fma(-l10, y1, z0))) * i0;
+    const double s = rsqrt(fma(y0, y0, fma(y1, y1, fma(y2, y2, y3 * y3))));
+    y0 *= s; y1 *= s; y2 *= s; y3 *= s;
+    // B^-1 is positive definite, so the step keeps the vector's sign: compare as they are
+    const double change = fmax(fmax(fabs(y0 - x0), fabs(y1 - x1)), fmax(fabs(y2 - x2), fabs(y3 - x3)));
+    settled = change <= 1e-13;      // false for NaN
+    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+  }
+  x[0] = x0; x[1] = x1; x[2] = x2; x[3] = x3;
+  return settled;
+}
+
 // Unit right singular vector of the smallest singular value of A.
 __device__ __forceinline__ void smallest_right_singular_vector(double (&a)[4][4], double (&x)[4]) {
+  if (null_vector_by_inverse_iteration(a, x)) return;
   double v[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)

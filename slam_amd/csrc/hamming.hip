@@ -825,8 +825,10 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
              void *d_workspace, size_t workspace_bytes, void *stream, bool prepacked = false,
              const int32_t *d_q_cnt = nullptr, const int32_t *d_t_cnt = nullptr,
              uint8_t *d_keep = nullptr, double ratio = 0.0, const int32_t *d_out_off = nullptr,
-             int n_out_total = -1, bool best_only = false, int pinned_splits = 0) {
+             int n_out_total = -1, bool best_only = false, int pinned_splits = 0,
+             slamhip_internal::Knn2Splits *unfolded = nullptr) {
   if (n_out_total < 0) n_out_total = nq_total;
+  if (unfolded != nullptr) { unfolded->part = nullptr; unfolded->splits = 1; unfolded->rows = n_out_total; }
   if (nq_total < 0 || nt_total < 0 || n_pairs < 1 || max_nq < 0 || max_nt < 0)
     return SLAMHIP_EINVAL;
   if (desc_bytes < 1 || row_stride < desc_bytes) return SLAMHIP_EINVAL;
@@ -934,6 +936,9 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 
   if (p.fold_in_kernel) {
     // folded and ratio-tested by the kernel itself
+  } else if (p.splits > 1 && unfolded != nullptr && d_keep == nullptr) {
+    unfolded->part = part;     // the caller's next kernel folds the splits
+    unfolded->splits = p.splits;
   } else if (p.splits > 1) {
     if (p.splits >= 16)
       hipLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
@@ -1012,6 +1017,8 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 9) g_raw_rows = value ? 1 : 0;
   else if (knob == 11) slamhip_internal::g_xcd_remap = value ? 1 : 0;
   else if (knob == 13) slamhip_internal::g_wide_rounds = (value >= 1 && value <= 3) ? value : 2;
+  else if (knob == 14) slamhip_internal::g_small_call_fusion = value ? 1 : 0;
+  else if (knob == 15) slamhip_internal::g_small_call_span = value > 0 ? (value + 1) & ~1 : 0;
   else if (knob == 10) g_prof_repeat = value >= 1 && value <= 64 ? value : 1;
   else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
   else return SLAMHIP_EINVAL;
@@ -1222,10 +1229,12 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
          int row_stride, bool prepacked, const int32_t *d_q_off, const int32_t *d_q_cnt,
          const int32_t *d_t_off, const int32_t *d_t_cnt, int n_pairs, int max_nq, int max_nt,
          int32_t *d_idx2, int32_t *d_dist2, void *d_workspace, size_t workspace_bytes,
-         hipStream_t st, const int32_t *d_out_off, int n_out_total, bool best_only, int splits) {
+         hipStream_t st, const int32_t *d_out_off, int n_out_total, bool best_only, int splits,
+         Knn2Splits *unfolded) {
   return run_knn2(d_query, nq_total, d_train, nt_total, desc_bytes, row_stride, d_q_off, d_t_off,
                   n_pairs, max_nq, max_nt, d_idx2, d_dist2, d_workspace, workspace_bytes, (void *)st,
-                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total, best_only, splits);
+                  prepacked, d_q_cnt, d_t_cnt, nullptr, 0.0, d_out_off, n_out_total, best_only, splits,
+                  unfolded);
 }
 
 int pack_rows(const uint8_t *d_a, int n_a, uint32_t *d_dst_a, const uint8_t *d_b, int n_b,

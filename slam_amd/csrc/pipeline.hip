@@ -20,6 +20,7 @@
 #include "dlt_device.h"
 #include "p3p_device.h"
 #include "ransac_device.h"
+#include "refine_device.h"
 #include "sort_device.h"
 
 namespace {
@@ -166,6 +167,154 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_sort_compact_kernel(
     __syncthreads();
   }
   if (threadIdx.x == 0) st_count[f] = running;
+}
+
+// A call of a few frames (the frame-at-a-time use of the reference's own loop,
+// fill_database.py:140) is a chain of dependent launches of one or a few workgroups each, and
+// every launch in the chain costs some 3.5 us before it does anything.  For such calls the
+// whole stereo stage behind the matcher is ONE launch, one workgroup per frame: fold of the
+// matcher's train splits (its merge launch is left out), sort by distance, filter and
+// compaction as in stereo_sort_compact_kernel, then what stereo_points_kernel does for the
+// survivors.  The sorted order, the matches' train rows and the survivors' left rows stay in
+// LDS instead of going through memory between launches.  Same results as the separate launches.
+//   part != nullptr: part[split * part_rows + off_left[f] + i] holds the (best, second best) key
+//   of left row i within train split `split` (key = distance << 21 | right row, 0xFFFFFFFF =
+//   none); else the folded result is in idx2 / dist2.
+template <int CAP>
+struct StereoTailLds {
+  RadixSortLds<kCompactBlock, CAP> sort;
+  int32_t train[CAP];
+  int wave_tot[kCompactBlock / 64];
+  int running;
+};
+template <int CAP>
+__global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
+    const float *__restrict__ kp_left, const float *__restrict__ kp_right,
+    const int32_t *__restrict__ off_left, const int32_t *__restrict__ off_right,
+    const int32_t *__restrict__ idx2, const int32_t *__restrict__ dist2,
+    const uint2 *__restrict__ part, int splits, int part_rows, double pix_thresh, double disp_min,
+    int32_t *__restrict__ st_count, int32_t *__restrict__ st_left, int32_t *__restrict__ st_right,
+    int32_t *__restrict__ st_dist, float *__restrict__ st_pix_left, float *__restrict__ st_pix_right,
+    const uint32_t *__restrict__ packed_left, int W, const uint8_t *__restrict__ raw_left, int raw_stride,
+    int desc_bytes, size_t raw_bytes, CamPair cam, float *__restrict__ st_xyz, uint32_t *__restrict__ st_desc) {
+  __shared__ StereoTailLds<CAP> lds;
+  const int f = blockIdx.x;
+  const int base = off_left[f], nq = off_left[f + 1] - base, rbase = off_right[f];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) lds.running = 0;
+  if (nq <= 0 || nq > CAP) {       // block-uniform (the host launches this kernel only when every frame fits)
+    if (threadIdx.x == 0) st_count[f] = 0;
+    return;
+  }
+  for (int i = threadIdx.x; i < nq; i += kCompactBlock) {
+    int t, d;
+    if (part != nullptr) {
+      uint32_t best = 0xFFFFFFFFu;           // keys are unique: the smallest is (closest, lowest right row)
+      for (int s0 = 0; s0 < splits; s0 += 8) {
+        uint32_t k[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = part[(size_t)min(s0 + j, splits - 1) * part_rows + base + i].x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best = min(best, k[j]);
+      }
+      t = best == 0xFFFFFFFFu ? -1 : (int)(best & kSortIdxMask);
+      d = best == 0xFFFFFFFFu ? -1 : (int)(best >> kSortKeyShift);
+    } else {
+      t = idx2[2 * (size_t)(base + i)];
+      d = dist2[2 * (size_t)(base + i)];
+    }
+    lds.train[i] = t;
+    lds.sort.keys[0][i] = sort_key(d, i);
+  }
+  radix_sort_lds<kCompactBlock, CAP>(lds.sort, nq);
+  uint32_t *const left_of = lds.sort.keys[1];    // survivor -> left row, once the sort is done with the array
+  for (int chunk = 0; chunk < nq; chunk += kCompactBlock) {
+    const int r = chunk + (int)threadIdx.x;
+    bool keep = false;
+    int q = 0, t = -1, d = -1;
+    double uL = 0, vL = 0, uR = 0, vR = 0;
+    if (r < nq) {
+      const uint32_t key = lds.sort.keys[0][r];
+      q = (int)(key & kSortIdxMask);
+      t = lds.train[q];
+      d = (int)(key >> kSortKeyShift);
+      if (t >= 0) {
+        uL = (double)kp_left[2 * (size_t)(base + q)];
+        vL = (double)kp_left[2 * (size_t)(base + q) + 1];
+        uR = (double)kp_right[2 * (size_t)(rbase + t)];
+        vR = (double)kp_right[2 * (size_t)(rbase + t) + 1];
+        keep = stereo_keep(uL, vL, uR, vR, pix_thresh, disp_min);
+      }
+    }
+    const unsigned long long ballot = __ballot(keep);
+    const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
+    if (lane == 0) lds.wave_tot[wave] = __popcll(ballot);
+    __syncthreads();
+    int wave_base = 0, chunk_total = 0;
+#pragma unroll
+    for (int w = 0; w < kCompactBlock / 64; ++w) {
+      if (w < wave) wave_base += lds.wave_tot[w];
+      chunk_total += lds.wave_tot[w];
+    }
+    const int pos = lds.running + wave_base + prefix;
+    if (keep) {
+      const size_t o = (size_t)(base + pos);
+      left_of[pos] = (uint32_t)q;
+      st_left[o] = q;
+      st_right[o] = t;
+      st_dist[o] = d;
+      st_pix_left[2 * o + 0] = (float)uL;
+      st_pix_left[2 * o + 1] = (float)vL;
+      st_pix_right[2 * o + 0] = (float)uR;
+      st_pix_right[2 * o + 1] = (float)vR;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) lds.running += chunk_total;
+    __syncthreads();
+  }
+  const int m = lds.running;
+  if (threadIdx.x == 0) st_count[f] = m;
+  // the survivors' points: the pixels come back from the arrays this workgroup has just written
+  for (int i = threadIdx.x; i < m; i += kCompactBlock) {
+    const size_t o = (size_t)(base + i);
+    double x[4];
+    dlt_null_vector(cam, (double)st_pix_left[2 * o], (double)st_pix_left[2 * o + 1],
+                    (double)st_pix_right[2 * o], (double)st_pix_right[2 * o + 1], x);
+    const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
+    st_xyz[3 * o + 0] = x0 / x3;
+    st_xyz[3 * o + 1] = x1 / x3;
+    st_xyz[3 * o + 2] = x2 / x3;
+  }
+  // and their descriptor rows, in survivor order (as stereo_points_kernel)
+  const int lw = W == 8 ? 3 : (W == 16 ? 4 : 5);
+  const int cpr = W >> 2, lc = lw - 2;
+  uint4 *dst = reinterpret_cast<uint4 *>(st_desc);
+  if (raw_left == nullptr) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(packed_left);
+#pragma unroll 4
+    for (int e = threadIdx.x; e < m * cpr; e += kCompactBlock) {
+      const int r = e >> lc, c = e & (cpr - 1);
+      dst[(size_t)(base + r) * cpr + c] = src[(size_t)(base + (int)left_of[r]) * cpr + c];
+    }
+  } else {
+#pragma unroll 4
+    for (int e = threadIdx.x; e < m * cpr; e += kCompactBlock) {
+      const int r = e >> lc, c = e & (cpr - 1);
+      const int valid = desc_bytes - 16 * c;          // descriptor bytes from this chunk on
+      const size_t at = (size_t)(base + (int)left_of[r]) * raw_stride + 16 * c;
+      const size_t from = at + 16 <= raw_bytes ? at : raw_bytes - 16;
+      unsigned __int128 x;
+      __builtin_memcpy(&x, raw_left + from, 16);
+      const int back = (int)(at - from);
+      x >>= 8 * (back < 15 ? back : 15);
+      auto mk = [&](int j) {
+        const int nb = valid - 4 * j;
+        return nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : (1u << (8 * nb)) - 1u);
+      };
+      dst[(size_t)(base + r) * cpr + c] = make_uint4((uint32_t)x & mk(0), (uint32_t)(x >> 32) & mk(1),
+                                                     (uint32_t)(x >> 64) & mk(2), (uint32_t)(x >> 96) & mk(3));
+    }
+  }
 }
 
 // Second half of the stereo stage, over the compacted inliers only (every lane
@@ -358,6 +507,80 @@ __global__ __launch_bounds__(T) void temporal_sort_gather_kernel(
     tm_query[o] = q;
     tm_train[o] = t;
     tm_dist[o] = tdist2[2 * (size_t)(ob + q)];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) cx[3 * o + c] = xyz[3 * (size_t)(qb + q) + c];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      cpl[2 * o + c] = (float)pix_left[2 * (size_t)(tb + t) + c];
+      cpr[2 * o + c] = (float)pix_right[2 * (size_t)(tb + t) + c];
+    }
+  }
+}
+
+// The temporal stage behind the matcher as one launch for calls of a few pairs (see
+// stereo_tail_kernel): fold of the matcher's train splits, sort, gather.  Same results as the
+// merge launch + temporal_sort_gather_kernel.
+template <typename PIX, int T, int CAP>
+struct TemporalTailLds {
+  RadixSortLds<T, CAP> sort;
+  int32_t train[CAP];
+};
+template <typename PIX, int T, int CAP>
+__global__ __launch_bounds__(T) void temporal_tail_kernel(
+    const int32_t *__restrict__ qbase, const int32_t *__restrict__ qcnt,
+    const int32_t *__restrict__ tbase, const int32_t *__restrict__ tcnt,
+    const int32_t *__restrict__ obase, const int32_t *__restrict__ tidx2,
+    const int32_t *__restrict__ tdist2, const uint2 *__restrict__ part, int splits, int part_rows,
+    const float *__restrict__ xyz, const PIX *__restrict__ pix_left, const PIX *__restrict__ pix_right,
+    int32_t *__restrict__ tm_query, int32_t *__restrict__ tm_train, int32_t *__restrict__ tm_dist,
+    int32_t *__restrict__ tm_count, float *__restrict__ cx, float *__restrict__ cpl,
+    float *__restrict__ cpr) {
+  __shared__ TemporalTailLds<PIX, T, CAP> lds;
+  const int p = blockIdx.x;
+  const int qb = qbase[p], tb = tbase[p], ob = obase[p];
+  const int nsort = qcnt[p];
+  const int n = tcnt[p] > 0 ? nsort : 0;  // no train rows -> no matches
+  if (n <= 0 || n > CAP) {                // block-uniform
+    if (threadIdx.x == 0) tm_count[p] = 0;
+    return;
+  }
+  for (int i = threadIdx.x; i < n; i += T) {
+    int t, d;
+    if (part != nullptr) {
+      uint32_t best = 0xFFFFFFFFu;
+      for (int s0 = 0; s0 < splits; s0 += 8) {
+        uint32_t k[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) k[j] = part[(size_t)min(s0 + j, splits - 1) * part_rows + ob + i].x;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best = min(best, k[j]);
+      }
+      t = best == 0xFFFFFFFFu ? -1 : (int)(best & kSortIdxMask);
+      d = best == 0xFFFFFFFFu ? -1 : (int)(best >> kSortKeyShift);
+    } else {
+      t = tidx2[2 * (size_t)(ob + i)];
+      d = tdist2[2 * (size_t)(ob + i)];
+    }
+    lds.train[i] = t;
+    lds.sort.keys[0][i] = sort_key(d, i);
+  }
+  radix_sort_lds<T, CAP>(lds.sort, n);
+  for (int r = threadIdx.x; r < n; r += T) {
+    const uint32_t key = lds.sort.keys[0][r];
+    const int q = (int)(key & kSortIdxMask);
+    const int t = lds.train[q];
+    // query rows without a match sort last: the matches are a prefix of the sorted rows, and
+    // the row that ends it writes the count
+    const bool next_matched = r + 1 < n && lds.train[(int)(lds.sort.keys[0][r + 1] & kSortIdxMask)] >= 0;
+    if (t < 0) {
+      if (r == 0) tm_count[p] = 0;
+      continue;
+    }
+    if (!next_matched) tm_count[p] = r + 1;
+    const size_t o = (size_t)(ob + r);
+    tm_query[o] = q;
+    tm_train[o] = t;
+    tm_dist[o] = (int)(key >> kSortKeyShift);
 #pragma unroll
     for (int c = 0; c < 3; ++c) cx[3 * o + c] = xyz[3 * (size_t)(qb + q) + c];
 #pragma unroll
@@ -650,7 +873,7 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
 }
 
 // grid (point spans, slots * kHypPerRound / 64, pairs), one wavefront per block; a span is
-// `chunks_per_span` LDS-staged chunks of kPtsPerChunk correspondences.  The first
+// `span_points` correspondences (even), staged in LDS kPtsPerChunk at a time.  The first
 // rounds, which most pairs need, use one chunk per block for parallelism; later
 // rounds, which few pairs reach, use one block per 64 hypotheses so that a launch
 // with nothing left to do costs a few thousand empty blocks instead of tens of
@@ -773,7 +996,7 @@ __device__ __forceinline__ void ransac_count_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     const RansacCam &cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,
-    const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32,
+    const int32_t *__restrict__ info, int span_points, int slots, const float *__restrict__ hyp32,
     int n_pairs) {
   __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
   // n_pairs > 0: grid (pairs rounded up to a multiple of 8, point spans, slots * kHypPerRound / 64):
@@ -786,7 +1009,7 @@ __device__ __forceinline__ void ransac_count_body(
   if (by_pair && p >= n_pairs) return;
   const int span = by_pair ? blockIdx.y : blockIdx.x, gy = by_pair ? blockIdx.z : blockIdx.y;
   ransac_count_item<MODE>(lds, p, (size_t)p * slots + gy / (kHypPerRound / 64), gy % (kHypPerRound / 64),
-                          span * (chunks_per_span * kPtsPerChunk), chunks_per_span * kPtsPerChunk, obase,
+                          span * span_points, span_points, obase,
                           tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, hyp32);
 }
 
@@ -821,10 +1044,10 @@ __device__ __forceinline__ void ransac_count_list_body(
   const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,                         \
       const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,  \
       RansacCam cam, double thresh, const double *__restrict__ rt, int32_t *__restrict__ counts,   \
-      const int32_t *__restrict__ info, int chunks_per_span, int slots, const float *__restrict__ hyp32, \
+      const int32_t *__restrict__ info, int span_points, int slots, const float *__restrict__ hyp32, \
       int n_pairs
 #define SLAMHIP_COUNT_PASS \
-  obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, chunks_per_span, slots, hyp32, n_pairs
+  obase, tm_count, cx, cpl, cpr, cam, thresh, rt, counts, info, span_points, slots, hyp32, n_pairs
 
 __global__ __launch_bounds__(64) void ransac_count_fp64_kernel(SLAMHIP_COUNT_ARGS) {
   ransac_count_body<0>(SLAMHIP_COUNT_PASS);
@@ -857,13 +1080,24 @@ void ransac_count_list_rectified_kernel(SLAMHIP_COUNT_ARGS, const int32_t *__res
 // Replays the hypothesis blocks not replayed yet (the last round's one, or all
 // `slots` of a single-pass call, in order), then writes the winner's mask, its
 // count and the final info record.  `first_block` = index of the first of them.
+// `seg_end` (may be null): seg_end[p] = one past the last mask row that belongs to pair p
+// (pairs' segments follow each other); the rows behind the pair's matches are cleared, and the
+// launch's last pair also clears the segment after its own when `clear_after_last` is set (the
+// last frame of a front-end call, which is the earlier frame of no pair) -- the caller's mask
+// array then needs no fill before the call.
+// REFINE: the pose refinement on the winner's inliers (refine.hip) follows in the same workgroup,
+// for calls whose launches, not arithmetic, bound them; same results as the separate launch.
+template <bool REFINE>
 __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
     int first_block, int slots, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
     const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
     RansacParams prm, const double *__restrict__ rt, const int32_t *__restrict__ counts,
-    double *__restrict__ pose_ransac, uint8_t *__restrict__ tm_mask, int32_t *__restrict__ info) {
+    double *__restrict__ pose_ransac, uint8_t *__restrict__ tm_mask, int32_t *__restrict__ info,
+    const int32_t *__restrict__ seg_end, int clear_after_last, Intr intr, int refine_iters,
+    double *__restrict__ pose_refined) {
   __shared__ int sh[3];  // winner lane, have a best hypothesis, mask count
   __shared__ double best_rt[12];
+  __shared__ RefineLds refine_lds;
   const int p = blockIdx.x;
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
@@ -910,8 +1144,15 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
     tm_mask[base + i] = in ? 1 : 0;
     if (in) atomicAdd(&sh[2], 1);
   }
+  if (seg_end != nullptr) {
+    const int last = (clear_after_last && p == (int)gridDim.x - 1) ? seg_end[p + 1] : seg_end[p];
+    for (size_t i = base + n + threadIdx.x; i < (size_t)last; i += kBlock) tm_mask[i] = 0;
+  }
   __syncthreads();
   if (threadIdx.x == 0) { s[5] = n; s[6] = sh[2]; s[7] = 0; }
+  if (REFINE)   // the mask rows this workgroup has written come back from memory behind the barrier above
+    refine_problem<float>(X, mL, tm_mask + base, n, best_rt, intr, refine_iters, pose_refined + 12 * (size_t)p,
+                          (double *)nullptr, refine_lds);
 }
 
 // A call with few pairs is bound by its dependent launches, not by arithmetic: it
@@ -922,6 +1163,7 @@ constexpr int kMaxSlots = 16;
 constexpr int kPairsPerXcdDeal = 64;     // pairs from which the counting launch deals its blocks to the XCDs by pair
 constexpr int kTailGrid = 4096;         // wavefronts of the merged tail's counting launch: 4 per SIMD
 constexpr int kSinglePassPairs = 64;    // measured break-even against the adaptive rounds at ~40 % inliers
+constexpr int kSmallCallBlocks = 2048;  // one-wavefront blocks the consensus count of a call of a few pairs aims at
 
 int single_pass_slots(int n_pairs, int n_iter_max) {
   const int slots = slamhip_ceil_div(n_iter_max > 0 ? n_iter_max : 1, kHypPerRound);
@@ -977,10 +1219,21 @@ size_t ransac_workspace_bytes(int n_pairs, int n_iter_max, bool merge_tail = fal
 
 // RANSAC for pairs [0, n_pairs) described by obase / tm_count; `prm.pair0` is
 // the first pair's index for sampling.  max_points bounds tm_count.
+// What the finishing launch does beyond the replay and the mask (ransac_finish_kernel).
+struct FinishExtras {
+  const int32_t *seg_end = nullptr;   // per pair: one past its last mask row; rows behind the matches are cleared
+  bool clear_after_last = false;      // the call's last pair also clears the segment behind its own
+  bool refine = false;                // the refinement follows in the same launch ...
+  Intr intr;                          // ... with these intrinsics,
+  int refine_iters = 0;               // this pass limit,
+  double *pose_refined = nullptr;     // into this array (12 doubles a pair)
+};
+
 int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *cx, const float *cpl,
                     const float *cpr, const int32_t *samples, RansacParams prm, int n_pairs,
                     int max_points, double *pose_ransac, uint8_t *tm_mask, int32_t *info, void *ws,
-                    hipStream_t st, bool merge_tail = false, bool mostly_unrelated = false) {
+                    hipStream_t st, bool merge_tail = false, bool mostly_unrelated = false,
+                    const FinishExtras &fx = FinishExtras()) {
   if (n_pairs <= 0) return SLAMHIP_OK;
   const int group = n_pairs < kPairGroup ? n_pairs : kPairGroup;
   const int slots = single_pass_slots(n_pairs, prm.n_iter_max);
@@ -1019,10 +1272,23 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       // a pair's blocks on one XCD where there are pairs enough to load the eight evenly (measured:
       // 499 pairs of ~600 points 59 -> 41 us per launch; 59 ragged pairs 201 -> 256 us)
       const bool by_pair = np >= kPairsPerXcdDeal;
-      const int spans = slamhip_ceil_div(chunks, per_span), groups = slots * (kHypPerRound / 64);
+      const int groups = slots * (kHypPerRound / 64);
+      // Correspondences per one-wavefront block: a chunk (or all of them, above).  A call of a pair
+      // or two leaves most of the chip idle with that and waits for each wavefront's walk over its
+      // 128 correspondences: there a block takes fewer, down to 32, while the launch stays within
+      // some two thousand blocks.
+      int span_points = per_span * kPtsPerChunk;
+      if (slots > 1 && slamhip_internal::g_small_call_fusion) {
+        const long long work = (long long)np * groups * (max_points > 0 ? max_points : 1);
+        int sp = (int)((work / kSmallCallBlocks + 31) / 32 * 32);
+        if (slamhip_internal::g_small_call_span > 0) sp = slamhip_internal::g_small_call_span;
+        if (sp < 32) sp = 32;
+        if (sp < span_points) span_points = sp;
+      }
+      const int spans = slamhip_ceil_div(max_points > 0 ? max_points : 1, span_points);
       const dim3 cgrid = by_pair ? dim3((np + 7) / 8 * 8, spans, groups) : dim3(spans, groups, np);
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
-                         prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, per_span, slots,
+                         prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, span_points, slots,
                          (const float *)hyp32, by_pair ? np : 0);
     }
     if (tail) {
@@ -1041,13 +1307,16 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       hipLaunchKernelGGL(count_list, dim3((unsigned)(most < kTailGrid ? most : kTailGrid)), dim3(64), 0, st,
                          obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt_tail, counts_tail,
                          info + 8 * (size_t)g0, chunks, tail, (const float *)nullptr, np, (const int32_t *)list);
-      hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, wide, tail,
-                         obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt_tail, counts_tail,
-                         pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
-    } else {
-      hipLaunchKernelGGL(ransac_finish_kernel, dim3(np), dim3(kBlock), 0, st, rounds - 1, slots,
-                         obase + g0, tm_count + g0, cx, cpl, cpr, prm, rt, counts,
-                         pose_ransac + 12 * (size_t)g0, tm_mask, info + 8 * (size_t)g0);
+    }
+    {
+      const int32_t *seg_end = fx.seg_end != nullptr ? fx.seg_end + g0 : nullptr;
+      const int clear_after = (fx.clear_after_last && g0 + np == n_pairs) ? 1 : 0;
+      double *refined = fx.pose_refined != nullptr ? fx.pose_refined + 12 * (size_t)g0 : nullptr;
+      auto finish = fx.refine ? ransac_finish_kernel<true> : ransac_finish_kernel<false>;
+      hipLaunchKernelGGL(finish, dim3(np), dim3(kBlock), 0, st, tail ? wide : rounds - 1, tail ? tail : slots,
+                         obase + g0, tm_count + g0, cx, cpl, cpr, prm, tail ? rt_tail : rt,
+                         tail ? counts_tail : counts, pose_ransac + 12 * (size_t)g0, tm_mask,
+                         info + 8 * (size_t)g0, seg_end, clear_after, fx.intr, fx.refine_iters, refined);
     }
     SLAMHIP_CHECK_LAUNCH();
   }
@@ -1063,6 +1332,7 @@ struct Layout {
 };
 
 constexpr int kInPlaceRows = 4096;   // features per image up to which the stereo matcher reads unpacked rows
+constexpr int kSmallCallFrames = 3;  // frames up to which a front-end call runs its stages as fused launches
 
 Layout make_layout(const slamhip_frontend_args *a) {
   Layout L;
@@ -1185,11 +1455,16 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   }
   int32_t *ridx2 = (int32_t *)(base + L.ridx2), *rdist2 = (int32_t *)(base + L.rdist2);
   uint32_t *bid = (uint32_t *)(base + L.bid);
+  // A call of a few frames runs its stages as fused launches (stereo_tail_kernel,
+  // temporal_tail_kernel, refinement behind the RANSAC replay): same results, a shorter chain.
+  const bool fused_sort = slamhip_internal::sort_choice() == 0 && a->max_left <= kFusedSortMax;
+  const bool small_call = slamhip_internal::g_small_call_fusion != 0 && F <= kSmallCallFrames && fused_sort;
+  slamhip_internal::Knn2Splits unfolded = {nullptr, 1, 0};
   if (!a->stereo_cross_check) {
     rc = slamhip_internal::knn2(rowsL, a->n_left_total, rowsR,
                                 a->n_right_total, a->desc_bytes, rows_stride, !L.raw, a->d_off_left, nullptr,
                                 a->d_off_right, nullptr, F, a->max_left, a->max_right, idx2, dist2,
-                                knn_ws, L.knn_bytes, st, nullptr, -1, true);
+                                knn_ws, L.knn_bytes, st, nullptr, -1, true, 0, small_call ? &unfolded : nullptr);
     if (rc) return rc;
   } else {
     if (hipMemsetAsync(bid, 0xFF, sizeof(uint32_t) * (size_t)a->n_left_total, st) != hipSuccess)
@@ -1210,10 +1485,18 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   }
   // sort by distance + filter + compaction: one launch where a frame's matches fit a block's LDS
   // (and no sort algorithm is forced), else the sort's launch and the compaction's
-  const bool fused_sort = slamhip_internal::sort_choice() == 0 && a->max_left <= kFusedSortMax;
   CamPair cam;
   for (int i = 0; i < 12; ++i) { cam.PL[i] = a->P_left[i]; cam.PR[i] = a->P_right[i]; }
-  if (fused_sort) {
+  const size_t raw_bytes = (size_t)(a->n_left_total - 1) * a->desc_stride + a->desc_bytes;
+  if (small_call) {
+    auto k = a->max_left <= 2048 ? stereo_tail_kernel<2048> : stereo_tail_kernel<kFusedSortMax>;
+    hipLaunchKernelGGL(k, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, a->d_off_left,
+                       a->d_off_right, idx2, dist2, unfolded.part, unfolded.splits, unfolded.rows,
+                       a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
+                       a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right, packL, W,
+                       L.raw ? a->d_des_left : nullptr, a->desc_stride, a->desc_bytes, raw_bytes, cam,
+                       a->d_st_xyz, a->d_st_desc);
+  } else if (fused_sort) {
     auto k = a->max_left <= 2048 ? stereo_sort_compact_kernel<2048> : stereo_sort_compact_kernel<kFusedSortMax>;
     hipLaunchKernelGGL(k, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, a->d_off_left,
                        a->d_off_right, idx2, dist2, a->pixel_thresh, a->disparity_min, a->d_st_count,
@@ -1226,12 +1509,11 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                        a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
                        a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
   }
-  hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F), dim3(kBlock),
-                     0, st, a->d_off_left, a->d_st_count, a->d_st_left, a->d_st_pix_left,
-                     a->d_st_pix_right, packL, W, L.raw ? a->d_des_left : nullptr, a->desc_stride,
-                     a->desc_bytes,
-                     (size_t)(a->n_left_total - 1) * a->desc_stride + a->desc_bytes, cam, a->d_st_xyz,
-                     a->d_st_desc);
+  if (!small_call)
+    hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F), dim3(kBlock),
+                       0, st, a->d_off_left, a->d_st_count, a->d_st_left, a->d_st_pix_left,
+                       a->d_st_pix_right, packL, W, L.raw ? a->d_des_left : nullptr, a->desc_stride,
+                       a->desc_bytes, raw_bytes, cam, a->d_st_xyz, a->d_st_desc);
   SLAMHIP_CHECK_LAUNCH();
   if (F < 2) return SLAMHIP_OK;
 
@@ -1241,7 +1523,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                                 (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
                                 true, a->d_off_left, a->d_st_count, a->d_off_left + 1,
                                 a->d_st_count + 1, F - 1, a->max_left, a->max_left, tidx2, tdist2, knn_ws,
-                                L.knn_bytes, st, nullptr, -1, true);
+                                L.knn_bytes, st, nullptr, -1, true, 0, small_call ? &unfolded : nullptr);
     if (rc) return rc;
   } else {
     // the inliers of frame p+1 choose among those of frame p, then bid for them
@@ -1259,7 +1541,15 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
                        dim3(kBlock), 0, st, bid, a->n_left_total, tidx2, tdist2);
     SLAMHIP_CHECK_LAUNCH();
   }
-  if (fused_sort) {
+  if (small_call) {
+    if (a->temporal_cross_check) unfolded = {nullptr, 1, 0};
+    auto k = a->max_left <= 2048 ? temporal_tail_kernel<float, 1024, 2048>
+                                 : temporal_tail_kernel<float, 1024, kFusedSortMax>;
+    hipLaunchKernelGGL(k, dim3(F - 1), dim3(1024), 0, st, a->d_off_left, a->d_st_count, a->d_off_left + 1,
+                       a->d_st_count + 1, a->d_off_left, tidx2, tdist2, unfolded.part, unfolded.splits,
+                       unfolded.rows, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_tm_query,
+                       a->d_tm_train, a->d_tm_dist, tcount, cx, cpl, cpr);
+  } else if (fused_sort) {
     // many short pairs: 256 threads a block; few long ones: 1024
     auto k = a->max_left <= 2048 ? temporal_sort_gather_kernel<float, 256, 2048>
                                  : temporal_sort_gather_kernel<float, 1024, kFusedSortMax>;
@@ -1291,10 +1581,19 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   prm.pair0 = 0;
   prm.seq0 = a->first_pair;
   prm.pair_ids = nullptr;
+  // the finishing launch leaves no mask row of the call unwritten (the caller's array needs no fill)
+  // and, in a call of a few frames, goes on to refine the winner
+  FinishExtras fx;
+  fx.seg_end = a->d_off_left + 1;
+  fx.clear_after_last = true;
+  fx.refine = small_call;
+  for (int i = 0; i < 9; ++i) fx.intr.K[i] = a->K[i];
+  fx.refine_iters = a->refine_iters;
+  fx.pose_refined = a->d_pose_refined;
   rc = run_pair_ransac(a->d_off_left, tcount, cx, cpl, cpr, a->d_samples, prm, F - 1, a->max_left,
                        a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st,
-                       /*merge_tail=*/true);
-  if (rc) return rc;
+                       /*merge_tail=*/true, /*mostly_unrelated=*/false, fx);
+  if (rc || small_call) return rc;
 
   rc = slamhip_internal::refine_pose(cx, 0, cpl, a->d_tm_mask, a->d_off_left, tcount, F - 1, a->K,
                                      a->d_pose_ransac, a->refine_iters, a->d_pose_refined, nullptr, st);

@@ -694,3 +694,55 @@ def test_any_number_of_rounds_before_the_merged_tail_gives_the_same_results():
                 assert it.min() < 256 < it.max(), (it.min(), it.max())   # first round and beyond
     finally:
         _lib.lib.slamhip_tune(13, 2)
+
+
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("F,nfeat,nbytes", [(2, (1200, 1600), 61), (3, (100, 2600), 61), (2, (2100, 5000), 32),
+                                            (3, (40, 700), 100)])
+def test_calls_of_a_few_frames_run_fused_launches_with_the_same_results(cross, F, nfeat, nbytes):
+    """A front-end call of up to three frames (the frame-at-a-time use of the reference's own loop,
+    fill_database.py:140) folds the matcher's train splits in the launch behind the matcher, runs
+    sort + filter + triangulation + descriptor gather as one launch, the refinement behind the RANSAC
+    replay, and deals the consensus count in shorter spans (tune knobs 14 / 15).  Every output must
+    equal that of the launches a long call uses: ragged frames, a frame of three features, both
+    matcher read modes, with and without cross-check."""
+    from slam_amd import CameraModel, _lib
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    seq = StereoSequence(cam, n_frames=F, n_features=nfeat, seed=23 + cross + F, clutter=0.6)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(F))]
+    if nbytes != 61:
+        widen = lambda d: (np.concatenate([d, d[:, :nbytes - 61] ^ 0x5A], axis=1) if nbytes > 61 else d[:, :nbytes]).copy()
+        frames = [(kl, kr, widen(dl), widen(dr)) for kl, kr, dl, dr in frames]
+    if F == 3:
+        frames[1] = tuple(a[:3] for a in frames[1])        # a frame of three features
+    fe = TrackingFrontend(cam, n_iter_max=700, seed=5, stereo_cross_check=cross, frame_cross_check=cross)
+    inp = fe.upload(frames)
+
+    def run():
+        res = fe.run(inp)
+        rows = [res.frame(f) for f in range(F)] + [res.pair(p) for p in range(F - 1)]
+        return [{k: np.array(v, copy=True) for k, v in r.items()} for r in rows]
+
+    try:
+        _lib.lib.slamhip_tune(14, 0)
+        want = run()
+        _lib.lib.slamhip_tune(14, 1)
+        got = [run()]
+        for span in (32, 64, 200):
+            _lib.lib.slamhip_tune(15, span)
+            got.append(run())
+        _lib.lib.slamhip_tune(15, 0)
+        _lib.lib.slamhip_tune(9, 0)          # the matcher reads packed rows
+        got.append(run())
+    finally:
+        _lib.lib.slamhip_tune(14, 1)
+        _lib.lib.slamhip_tune(15, 0)
+        _lib.lib.slamhip_tune(9, 1)
+    assert sum(len(r["xyz"]) for r in want[:F]) > 100
+    for other in got:
+        for x, y in zip(want, other):
+            assert x.keys() == y.keys()
+            for k in x:
+                np.testing.assert_array_equal(x[k], y[k], err_msg=k)

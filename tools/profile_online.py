@@ -9,6 +9,11 @@ from slam_amd.backend.tracking.frontend import TrackingFrontend
 from slam_amd.utils.synth import StereoSequence
 
 nfeat = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
+# further arguments: knob=value pairs for slamhip_tune (e.g. 14=0: the launches of a long call)
+from slam_amd import _lib
+for kv in sys.argv[2:]:
+    k, v = kv.split("=")
+    assert _lib.lib.slamhip_tune(int(k), int(v)) == 0
 cam = CameraModel.kitti_like()
 seq = StereoSequence(cam, n_frames=2, n_features=nfeat, seed=3, clutter=0.6)
 frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(2))]
@@ -21,4 +26,4 @@ t0 = time.perf_counter()
 for _ in range(300):
     fe.run(inp)
 torch.cuda.synchronize()
-print(f"one pair of {nfeat}-feature frames: {(time.perf_counter() - t0) / 300 * 1e6:.1f} us per call")
+print(f"{sys.argv[2:]} one pair of {nfeat}-feature frames: {(time.perf_counter() - t0) / 300 * 1e6:.1f} us per call")
