@@ -472,16 +472,22 @@ def bench_sequence(args, rank, world, dist, red_dev="cuda"):
 
 
 def bench_online(args):
-    """The reference's own calling pattern (fill_database.py:140: one frame at a time): one
-    front-end call per new frame, two frames per call, features resident."""
+    """The reference's own calling pattern (fill_database.py:140: one frame at a time).
+    online_pair_us: one front-end call per new frame, two frames per call, features resident
+    (the device-side chain).  online_push_us: OnlineFrontend.push of a new frame held in host
+    arrays (upload of that frame alone, one library call that carries the previous frame's
+    stereo stage over) followed by pose(), i.e. features in host memory to relative pose in
+    host memory, one frame at a time."""
     from slam_amd import CameraModel
     from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.backend.tracking.online import OnlineFrontend
     from slam_amd.utils.synth import StereoSequence
     cam = CameraModel.kitti_like()
-    seq = StereoSequence(cam, n_frames=2, n_features=1500, seed=3, clutter=0.63, landmark_density=0.58)
-    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(2))]
+    n_seq = 24
+    seq = StereoSequence(cam, n_frames=n_seq, n_features=1500, seed=3, clutter=0.63, landmark_density=0.58)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(n_seq))]
     fe = TrackingFrontend(cam)
-    inp = fe.upload(frames)
+    inp = fe.upload(frames[:2])
     for _ in range(20):
         fe.run(inp)
     torch.cuda.synchronize()
@@ -491,11 +497,27 @@ def bench_online(args):
         fe.run(inp)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
+    online = OnlineFrontend(cam)
+    for f in frames[:4]:
+        r = online.push(*f)
+    r.pose()
+    online.reset()
+    online.push(*frames[0])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    inl = []
+    for f in frames[1:]:
+        Rt, info = online.push(*f).pose()
+        inl.append(info[6] / max(info[5], 1))
+    dt_push = (time.perf_counter() - t0) / (n_seq - 1)
     return {"online_pair_us": dt * 1e6, "frames_per_sec": 1.0 / dt,
-            "note": "one pair of 1500-feature frames per call; the call is a chain of about ten dependent "
-                    "launches whose own durations add up to nearly all of it (profiles/r3/online_kernel_stats.csv): "
-                    "one block per frame or pair in most of them, so latency of the kernels, not launch "
-                    "overhead, is what a single-launch version would have to remove"}
+            "online_push_us": dt_push * 1e6, "push_frames_per_sec": 1.0 / dt_push,
+            "push_inlier_ratio_mean": float(np.mean(inl)),
+            "note": "online_pair_us: one pair of 1500-feature frames per call, features resident: seven "
+                    "dependent launches (matcher, fused stereo tail, matcher, fused temporal tail, P3P, "
+                    "consensus count, replay + mask + refinement), each one or a few workgroups running a "
+                    "dependent chain; online_push_us: OnlineFrontend.push(frame in host arrays).pose(), "
+                    "which includes the upload of the new frame, the call and the pose's way back"}
 
 
 def bench_sweep(kernels, mfma=False):

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define SLAMHIP_VERSION 102 /* 0.1.2: struct_size leads the two argument structs; d_samples for pair verification */
+#define SLAMHIP_VERSION 103 /* 0.1.3: slamhip_frontend_args.first_stereo_frame (frame-at-a-time calls) */
 
 enum {
   SLAMHIP_OK = 0,
@@ -381,7 +381,9 @@ typedef struct slamhip_frontend_args {
                                             padded to W = 8/16/32 dwords */
   int32_t *d_tm_query, *d_tm_train, *d_tm_dist; /* n_left_total: sorted temporal matches of pair f
                                             at d_off_left[f] (indices into the inlier sets) */
-  uint8_t *d_tm_mask;                    /* n_left_total: RANSAC inlier mask, same order */
+  uint8_t *d_tm_mask;                    /* n_left_total: RANSAC inlier mask, same order; a call with
+                                            F >= 2 writes every row (zero behind a pair's matches and
+                                            for the last frame): no fill needed beforehand */
   double *d_pose_ransac, *d_pose_refined;/* (F-1)*12: winning hypothesis, refined [R|t] */
   int32_t *d_ransac_info;                /* (F-1)*8: best index, best count, iterations, final
                                             n_iter_required, math-domain flag, N, mask count, 0 */
@@ -391,6 +393,16 @@ typedef struct slamhip_frontend_args {
                                 whole sequence: the device sampler draws pair p's samples from
                                 (seed, first_pair + p), so a sequence cut into batches or shards
                                 gets the samples of the uncut run.  d_samples rows stay local. */
+  int32_t first_stereo_frame;/* 0 .. F-1: the stereo stage runs for frames [first_stereo_frame, F)
+                                only; the d_st_* rows and d_st_count entries of the earlier frames
+                                are taken as they stand (written by an earlier call on the same
+                                arrays).  A caller that gets one frame at a time (the reference's
+                                own loop, fill_database.py:140-240, which carries the previous
+                                frame's stereo stage over, :234-240) keeps the last frame's rows
+                                in place, appends the new frame behind them and calls with F = 2,
+                                first_stereo_frame = 1, first_pair = the pair's number: the
+                                results are those of one call over the whole sequence. */
+  int32_t reserved0;
 } slamhip_frontend_args;
 
 size_t slamhip_frontend_workspace_bytes(const slamhip_frontend_args *args);

@@ -100,6 +100,7 @@ class FrontendArgs(C.Structure):
         ("d_pose_ransac", _vp), ("d_pose_refined", _vp), ("d_ransac_info", _vp),
         ("d_workspace", _vp), ("workspace_bytes", _sz),
         ("first_pair", C.c_int64),
+        ("first_stereo_frame", _i32), ("reserved0", _i32),
     ]
 
     def __init__(self, *a, **kw):

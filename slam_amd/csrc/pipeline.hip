@@ -1342,18 +1342,20 @@ Layout make_layout(const slamhip_frontend_args *a) {
   auto take = [&](size_t bytes) { const size_t at = o; o = slamhip_align_up(o + bytes, 256); return at; };
   L.idx2 = take(NL * 8); L.dist2 = take(NL * 8); L.order = take(NL * 4);
   const int F = a->n_frames > 0 ? a->n_frames : 1;
+  // frames whose stereo stage this call runs (the others' outputs are in place: first_stereo_frame)
+  const int Fs = (a->first_stereo_frame > 0 && a->first_stereo_frame < F) ? F - a->first_stereo_frame : F;
   // In place where the matcher's kernel can and a frame is a few query blocks: every one of them
   // reads the frame's train rows again, and the unaligned, masked read costs more than the aligned
   // one (measured per pass, in place against packed first: 500 frames of 1500 features 0.755 /
   // 0.779 ms, 250 of 3000 1.031 / 1.040, 100 of 2000-8000 1.67 / 1.65).
   L.raw = a->max_left <= kInPlaceRows && a->max_right <= kInPlaceRows &&
-          slamhip_internal::knn2_reads_raw(a->n_left_total, a->n_right_total, F, a->max_left,
+          slamhip_internal::knn2_reads_raw(a->n_left_total, a->n_right_total, Fs, a->max_left,
                                            a->max_right, a->desc_bytes) &&
           (!a->stereo_cross_check ||
-           slamhip_internal::knn2_reads_raw(a->n_right_total, a->n_left_total, F, a->max_right,
+           slamhip_internal::knn2_reads_raw(a->n_right_total, a->n_left_total, Fs, a->max_right,
                                             a->max_left, a->desc_bytes));
   L.packL = take(L.raw ? 0 : NL * L.W * 4); L.packR = take(L.raw ? 0 : NR * L.W * 4);
-  const size_t k1 = slamhip_internal::knn2_workspace_bytes(a->n_left_total, a->n_right_total, F,
+  const size_t k1 = slamhip_internal::knn2_workspace_bytes(a->n_left_total, a->n_right_total, Fs,
                                                            a->max_left, a->max_right, a->desc_bytes, -1, !L.raw);
   const size_t k2 = slamhip_internal::knn2_workspace_bytes(a->n_left_total, a->n_left_total,
                                                            F > 1 ? F - 1 : 1, a->max_left, a->max_left,
@@ -1361,7 +1363,7 @@ Layout make_layout(const slamhip_frontend_args *a) {
   L.knn_bytes = k1 > k2 ? k1 : k2;
   L.ridx2 = L.rdist2 = L.bid = 0;
   if (a->stereo_cross_check || a->temporal_cross_check) {
-    const size_t k3 = slamhip_internal::knn2_workspace_bytes(a->n_right_total, a->n_left_total, F,
+    const size_t k3 = slamhip_internal::knn2_workspace_bytes(a->n_right_total, a->n_left_total, Fs,
                                                              a->max_right, a->max_left, a->desc_bytes, -1, !L.raw);
     if (k3 > L.knn_bytes) L.knn_bytes = k3;
     const size_t rows = NL > NR ? NL : NR;
@@ -1408,6 +1410,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
     return SLAMHIP_EUNSUPPORTED;
   if (a->max_left < 0 || a->max_right < 0 || a->n_iter_max < 1 || a->refine_iters < 0)
     return SLAMHIP_EINVAL;
+  if (a->first_stereo_frame < 0 || a->first_stereo_frame >= a->n_frames) return SLAMHIP_EINVAL;
   if (!a->d_off_left || !a->d_off_right || !a->d_st_count) return SLAMHIP_EINVAL;
   if (a->n_left_total > 0 &&
       (!a->d_kp_left || !a->d_des_left || !a->d_st_left || !a->d_st_right || !a->d_st_dist ||
@@ -1430,10 +1433,14 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   float *cx = (float *)(base + L.cx), *cpl = (float *)(base + L.cpl), *cpr = (float *)(base + L.cpr);
   int32_t *tcount = (int32_t *)(base + L.tcount);
   const int F = a->n_frames, W = L.W;
+  // the stereo stage runs for frames [s0, F); the earlier frames' stereo outputs are in place
+  const int s0 = a->first_stereo_frame, Fs = F - s0;
+  const int32_t *const s_off_left = a->d_off_left + s0, *const s_off_right = a->d_off_right + s0;
+  int32_t *const s_st_count = a->d_st_count + s0;
   int rc;
 
   if (a->n_left_total == 0 || a->max_left == 0) {
-    if (hipMemsetAsync(a->d_st_count, 0, sizeof(int32_t) * F, st) != hipSuccess) return SLAMHIP_ELAUNCH;
+    if (hipMemsetAsync(s_st_count, 0, sizeof(int32_t) * Fs, st) != hipSuccess) return SLAMHIP_ELAUNCH;
     if (F > 1) {
       if (hipMemsetAsync(a->d_ransac_info, 0, sizeof(int32_t) * 8 * (F - 1), st) != hipSuccess)
         return SLAMHIP_ELAUNCH;
@@ -1462,8 +1469,8 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   slamhip_internal::Knn2Splits unfolded = {nullptr, 1, 0};
   if (!a->stereo_cross_check) {
     rc = slamhip_internal::knn2(rowsL, a->n_left_total, rowsR,
-                                a->n_right_total, a->desc_bytes, rows_stride, !L.raw, a->d_off_left, nullptr,
-                                a->d_off_right, nullptr, F, a->max_left, a->max_right, idx2, dist2,
+                                a->n_right_total, a->desc_bytes, rows_stride, !L.raw, s_off_left, nullptr,
+                                s_off_right, nullptr, Fs, a->max_left, a->max_right, idx2, dist2,
                                 knn_ws, L.knn_bytes, st, nullptr, -1, true, 0, small_call ? &unfolded : nullptr);
     if (rc) return rc;
   } else {
@@ -1471,12 +1478,12 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
       return SLAMHIP_ELAUNCH;
     if (a->n_right_total > 0 && a->max_right > 0) {
       rc = slamhip_internal::knn2(rowsR, a->n_right_total, rowsL,
-                                  a->n_left_total, a->desc_bytes, rows_stride, !L.raw, a->d_off_right, nullptr,
-                                  a->d_off_left, nullptr, F, a->max_right, a->max_left, ridx2, rdist2,
+                                  a->n_left_total, a->desc_bytes, rows_stride, !L.raw, s_off_right, nullptr,
+                                  s_off_left, nullptr, Fs, a->max_right, a->max_left, ridx2, rdist2,
                                   knn_ws, L.knn_bytes, st, nullptr, -1, true);
       if (rc) return rc;
-      hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_right, kBlock), F), dim3(kBlock),
-                         0, st, a->d_off_right, (const int32_t *)nullptr, a->d_off_left, ridx2, rdist2,
+      hipLaunchKernelGGL(cross_bid_kernel, dim3(slamhip_ceil_div(a->max_right, kBlock), Fs), dim3(kBlock),
+                         0, st, s_off_right, (const int32_t *)nullptr, s_off_left, ridx2, rdist2,
                          bid);
     }
     hipLaunchKernelGGL(cross_decode_kernel, dim3(slamhip_ceil_div(a->n_left_total, kBlock)),
@@ -1490,28 +1497,28 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   const size_t raw_bytes = (size_t)(a->n_left_total - 1) * a->desc_stride + a->desc_bytes;
   if (small_call) {
     auto k = a->max_left <= 2048 ? stereo_tail_kernel<2048> : stereo_tail_kernel<kFusedSortMax>;
-    hipLaunchKernelGGL(k, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, a->d_off_left,
-                       a->d_off_right, idx2, dist2, unfolded.part, unfolded.splits, unfolded.rows,
-                       a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
+    hipLaunchKernelGGL(k, dim3(Fs), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, s_off_left,
+                       s_off_right, idx2, dist2, unfolded.part, unfolded.splits, unfolded.rows,
+                       a->pixel_thresh, a->disparity_min, s_st_count, a->d_st_left, a->d_st_right,
                        a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right, packL, W,
                        L.raw ? a->d_des_left : nullptr, a->desc_stride, a->desc_bytes, raw_bytes, cam,
                        a->d_st_xyz, a->d_st_desc);
   } else if (fused_sort) {
     auto k = a->max_left <= 2048 ? stereo_sort_compact_kernel<2048> : stereo_sort_compact_kernel<kFusedSortMax>;
-    hipLaunchKernelGGL(k, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, a->d_off_left,
-                       a->d_off_right, idx2, dist2, a->pixel_thresh, a->disparity_min, a->d_st_count,
+    hipLaunchKernelGGL(k, dim3(Fs), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, s_off_left,
+                       s_off_right, idx2, dist2, a->pixel_thresh, a->disparity_min, s_st_count,
                        a->d_st_left, a->d_st_right, a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
   } else {
-    rc = slamhip_internal::sort_by_distance(dist2, 2, a->d_off_left, nullptr, F, a->max_left, order, st);
+    rc = slamhip_internal::sort_by_distance(dist2, 2, s_off_left, nullptr, Fs, a->max_left, order, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(stereo_compact_kernel, dim3(F), dim3(kCompactBlock), 0, st, a->d_kp_left,
-                       a->d_kp_right, a->d_off_left, a->d_off_right, idx2, dist2, order,
-                       a->pixel_thresh, a->disparity_min, a->d_st_count, a->d_st_left, a->d_st_right,
+    hipLaunchKernelGGL(stereo_compact_kernel, dim3(Fs), dim3(kCompactBlock), 0, st, a->d_kp_left,
+                       a->d_kp_right, s_off_left, s_off_right, idx2, dist2, order,
+                       a->pixel_thresh, a->disparity_min, s_st_count, a->d_st_left, a->d_st_right,
                        a->d_st_dist, a->d_st_pix_left, a->d_st_pix_right);
   }
   if (!small_call)
-    hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), F), dim3(kBlock),
-                       0, st, a->d_off_left, a->d_st_count, a->d_st_left, a->d_st_pix_left,
+    hipLaunchKernelGGL(stereo_points_kernel, dim3(slamhip_ceil_div(a->max_left, kBlock), Fs), dim3(kBlock),
+                       0, st, s_off_left, s_st_count, a->d_st_left, a->d_st_pix_left,
                        a->d_st_pix_right, packL, W, L.raw ? a->d_des_left : nullptr, a->desc_stride,
                        a->desc_bytes, raw_bytes, cam, a->d_st_xyz, a->d_st_desc);
   SLAMHIP_CHECK_LAUNCH();

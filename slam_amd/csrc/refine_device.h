@@ -9,6 +9,7 @@
 namespace slamhip_dev {
 
 constexpr int kRefThreads = 256;
+constexpr int kRefTermStride = kRefThreads + 2;   // doubles between the rows of two terms in LDS
 
 struct Intr { double K[9]; };
 
@@ -108,7 +109,7 @@ static __device__ bool solve_damped(const double *h, const double *g, double lam
 template <typename PT>
 __device__ void accumulate(const PT *__restrict__ pts, const float *__restrict__ pix,
                            const uint8_t *__restrict__ mask, int n, const double *Rt,
-                           const Intr &in, double *lds /* [4][28] */, double *out /* [28] */) {
+                           const Intr &in, double *lds /* RefineLds::lds */, double *out /* [28] */) {
   double acc[28];
 #pragma unroll
   for (int i = 0; i < 28; ++i) acc[i] = 0.0;
@@ -146,23 +147,37 @@ __device__ void accumulate(const PT *__restrict__ pts, const float *__restrict__
     for (int i = 0; i < 6; ++i) acc[21 + i] += ju[i] * ru + jv[i] * rv;
     acc[27] += ru * ru + rv * rv;
   }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // The 28 sums over the workgroup's 256 lanes, through LDS: every lane lays its terms down
+  // (term-major, a lane apart: no bank conflict on the way in), thread (term, part) adds the
+  // 32 lanes of its part, and the eight parts of a term meet in a second, short step.  Some
+  // hundred instructions a pass where 28 wavefront-wide sums through DPP took six hundred --
+  // a quarter of a pass, in a kernel that is a chain of such passes.
+  double *const terms = lds;                          // [28][kRefTermStride]
+  double *const parts = lds + 28 * kRefTermStride;    // [28][8]
 #pragma unroll
-  for (int i = 0; i < 28; ++i) {
-    const double s = wave_sum(acc[i]);
-    if (lane == 0) lds[wave * 28 + i] = s;
+  for (int i = 0; i < 28; ++i) terms[i * kRefTermStride + threadIdx.x] = acc[i];
+  __syncthreads();
+  {
+    const int term = threadIdx.x & 31, part = threadIdx.x >> 5;
+    if (term < 28) {
+      const double *src = terms + term * kRefTermStride + part * 32;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int r = 0; r < 32; r += 4) { s0 += src[r]; s1 += src[r + 1]; s2 += src[r + 2]; s3 += src[r + 3]; }
+      parts[term * 8 + part] = (s0 + s1) + (s2 + s3);
+    }
   }
   __syncthreads();
   if (threadIdx.x < 28) {
-    const int i = threadIdx.x;
-    out[i] = (lds[i] + lds[28 + i]) + (lds[56 + i] + lds[84 + i]);
+    const double *q = parts + threadIdx.x * 8;
+    out[threadIdx.x] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
   }
   __syncthreads();
 }
 
 // LDS of one refinement problem.
 struct RefineLds {
-  double lds[4 * 28];
+  double lds[28 * kRefTermStride + 28 * 8];
   double sums[28];
   double pose[12];   // current accepted pose
   double cand[12];   // candidate pose

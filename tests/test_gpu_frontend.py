@@ -746,3 +746,43 @@ def test_calls_of_a_few_frames_run_fused_launches_with_the_same_results(cross, F
             assert x.keys() == y.keys()
             for k in x:
                 np.testing.assert_array_equal(x[k], y[k], err_msg=k)
+
+
+@pytest.mark.parametrize("cross", [False, True])
+def test_pushing_frames_one_at_a_time_equals_the_batched_call(cross):
+    """OnlineFrontend.push is the reference's own calling pattern (one stereo frame per iteration,
+    the previous frame's stereo stage carried over, fill_database.py:140-240): each push uploads
+    the new frame only and runs one library call with first_stereo_frame = 1.  Frame by frame it
+    must give, bit for bit, what one batched call over the whole sequence gives -- through the
+    moves of the last frame to the front of the device arrays (a capacity of three frames), a
+    frame without right features, a frame of three features and a growing frame size."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    from slam_amd.backend.tracking.online import OnlineFrontend
+    from slam_amd.utils.synth import StereoSequence
+    cam = CameraModel.kitti_like()
+    F = 11
+    seq = StereoSequence(cam, n_frames=F, n_features=(300, 1500), seed=41 + cross, clutter=0.6)
+    frames = [(f.kp_left, f.kp_right, f.des_left, f.des_right) for f in (seq.frame(k) for k in range(F))]
+    frames[4] = (frames[4][0], np.zeros((0, 2), np.float32), frames[4][2], np.zeros((0, 61), np.uint8))
+    frames[7] = tuple(a[:3] for a in frames[7])
+    big = StereoSequence(cam, n_frames=F, n_features=4000, seed=43, clutter=0.6).frame(9)
+    frames[9] = (big.kp_left, big.kp_right, big.des_left, big.des_right)      # outgrows the arrays
+    kw = dict(n_iter_max=600, seed=11, stereo_cross_check=cross, frame_cross_check=cross)
+    want = TrackingFrontend(cam, **kw).run(frames)
+    online = OnlineFrontend(cam, frames_capacity=3, **kw)
+    assert online.push(*frames[0]) is None
+    for k in range(1, F):
+        got = online.push(*frames[k])
+        Rt, info = got.pose()
+        for (x, y) in ((got.frame(0), want.frame(k - 1)), (got.frame(1), want.frame(k)), (got.pair(0), want.pair(k - 1))):
+            assert x.keys() == y.keys()
+            for key in x:
+                np.testing.assert_array_equal(x[key], y[key], err_msg=f"frame {k}: {key}")
+        np.testing.assert_array_equal(Rt, want.pair(k - 1)["Rt"])
+        assert info[5] == want.pair(k - 1)["n_matches"]
+    assert sum(want.pair(p)["mask"].sum() for p in range(F - 1)) > 100
+    # a second sequence through the same object
+    online.reset()
+    assert online.push(*frames[1]) is None
+    np.testing.assert_array_equal(online.push(*frames[2]).pair(0)["query_idx"], want.pair(1)["query_idx"])
