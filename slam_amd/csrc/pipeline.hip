@@ -29,6 +29,19 @@ using namespace slamhip_dev;
 
 constexpr int kBlock = 256;
 
+// Timing experiment (-DSLAMHIP_STAMPS): the first workgroup of the fused launches of a small call
+// notes the 100 MHz clock at its phase boundaries; tools/stamps_small_call.py prints the phases.
+#ifdef SLAMHIP_STAMPS
+static __device__ unsigned long long g_stamps[64];
+#define SLAMHIP_STAMP(i)                                                                      \
+  do {                                                                                        \
+    __syncthreads();                                                                          \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_stamps[i] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#else
+#define SLAMHIP_STAMP(i)
+#endif
+
 // --------------------------------------------------------------------------
 // Stereo stage, first half: row/disparity filter + stable compaction (ballot
 // prefix) of the sorted matches.  One workgroup per frame walks them in chunks
@@ -184,8 +197,8 @@ template <int CAP>
 struct StereoTailLds {
   RadixSortLds<kCompactBlock, CAP> sort;
   int32_t train[CAP];
-  int wave_tot[kCompactBlock / 64];
-  int running;
+  float4 pix[CAP];                       // survivors' (uL, vL, uR, vR), in survivor order
+  int wave_tot[2][kCompactBlock / 64];
 };
 template <int CAP>
 __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
@@ -198,10 +211,10 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
     const uint32_t *__restrict__ packed_left, int W, const uint8_t *__restrict__ raw_left, int raw_stride,
     int desc_bytes, size_t raw_bytes, CamPair cam, float *__restrict__ st_xyz, uint32_t *__restrict__ st_desc) {
   __shared__ StereoTailLds<CAP> lds;
+  SLAMHIP_STAMP(0);
   const int f = blockIdx.x;
   const int base = off_left[f], nq = off_left[f + 1] - base, rbase = off_right[f];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) lds.running = 0;
   if (nq <= 0 || nq > CAP) {       // block-uniform (the host launches this kernel only when every frame fits)
     if (threadIdx.x == 0) st_count[f] = 0;
     return;
@@ -210,12 +223,12 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
     int t, d;
     if (part != nullptr) {
       uint32_t best = 0xFFFFFFFFu;           // keys are unique: the smallest is (closest, lowest right row)
-      for (int s0 = 0; s0 < splits; s0 += 8) {
-        uint32_t k[8];
+      for (int s0 = 0; s0 < splits; s0 += 16) {   // sixteen loads in flight (the matcher's usual split count)
+        uint32_t k[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) k[j] = part[(size_t)min(s0 + j, splits - 1) * part_rows + base + i].x;
+        for (int j = 0; j < 16; ++j) k[j] = part[(size_t)min(s0 + j, splits - 1) * part_rows + base + i].x;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) best = min(best, k[j]);
+        for (int j = 0; j < 16; ++j) best = min(best, k[j]);
       }
       t = best == 0xFFFFFFFFu ? -1 : (int)(best & kSortIdxMask);
       d = best == 0xFFFFFFFFu ? -1 : (int)(best >> kSortKeyShift);
@@ -226,65 +239,90 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
     lds.train[i] = t;
     lds.sort.keys[0][i] = sort_key(d, i);
   }
+  SLAMHIP_STAMP(1);
   radix_sort_lds<kCompactBlock, CAP>(lds.sort, nq);
+  SLAMHIP_STAMP(2);
   uint32_t *const left_of = lds.sort.keys[1];    // survivor -> left row, once the sort is done with the array
-  for (int chunk = 0; chunk < nq; chunk += kCompactBlock) {
-    const int r = chunk + (int)threadIdx.x;
-    bool keep = false;
-    int q = 0, t = -1, d = -1;
-    double uL = 0, vL = 0, uR = 0, vR = 0;
-    if (r < nq) {
-      const uint32_t key = lds.sort.keys[0][r];
-      q = (int)(key & kSortIdxMask);
-      t = lds.train[q];
-      d = (int)(key >> kSortKeyShift);
-      if (t >= 0) {
-        uL = (double)kp_left[2 * (size_t)(base + q)];
-        vL = (double)kp_left[2 * (size_t)(base + q) + 1];
-        uR = (double)kp_right[2 * (size_t)(rbase + t)];
-        vR = (double)kp_right[2 * (size_t)(rbase + t) + 1];
-        keep = stereo_keep(uL, vL, uR, vR, pix_thresh, disp_min);
+  // Filter, compaction and triangulation, two chunks of kCompactBlock sorted matches at a time: the
+  // matches and pixels of both chunks are fetched and judged first (their loads in flight together),
+  // one barrier makes the wavefronts' survivor counts known, and every survivor is then written to
+  // its place; its pixels also go to LDS, for the triangulation behind the loop.
+  constexpr int kGroup = 2;
+  int running = 0;
+  for (int chunk0 = 0; chunk0 < nq; chunk0 += kGroup * kCompactBlock) {
+    bool keep[kGroup];
+    int q[kGroup], t[kGroup], d[kGroup], prefix[kGroup];
+    double uL[kGroup], vL[kGroup], uR[kGroup], vR[kGroup];
+#pragma unroll
+    for (int c = 0; c < kGroup; ++c) {
+      const int r = chunk0 + c * kCompactBlock + (int)threadIdx.x;
+      keep[c] = false; q[c] = 0; t[c] = -1; d[c] = -1;
+      uL[c] = vL[c] = uR[c] = vR[c] = 0.0;
+      if (r < nq) {
+        const uint32_t key = lds.sort.keys[0][r];
+        q[c] = (int)(key & kSortIdxMask);
+        t[c] = lds.train[q[c]];
+        d[c] = (int)(key >> kSortKeyShift);
+        if (t[c] >= 0) {
+          uL[c] = (double)kp_left[2 * (size_t)(base + q[c])];
+          vL[c] = (double)kp_left[2 * (size_t)(base + q[c]) + 1];
+          uR[c] = (double)kp_right[2 * (size_t)(rbase + t[c])];
+          vR[c] = (double)kp_right[2 * (size_t)(rbase + t[c]) + 1];
+        }
       }
     }
-    const unsigned long long ballot = __ballot(keep);
-    const int prefix = __popcll(ballot & ((1ull << lane) - 1ull));
-    if (lane == 0) lds.wave_tot[wave] = __popcll(ballot);
-    __syncthreads();
-    int wave_base = 0, chunk_total = 0;
 #pragma unroll
-    for (int w = 0; w < kCompactBlock / 64; ++w) {
-      if (w < wave) wave_base += lds.wave_tot[w];
-      chunk_total += lds.wave_tot[w];
-    }
-    const int pos = lds.running + wave_base + prefix;
-    if (keep) {
-      const size_t o = (size_t)(base + pos);
-      left_of[pos] = (uint32_t)q;
-      st_left[o] = q;
-      st_right[o] = t;
-      st_dist[o] = d;
-      st_pix_left[2 * o + 0] = (float)uL;
-      st_pix_left[2 * o + 1] = (float)vL;
-      st_pix_right[2 * o + 0] = (float)uR;
-      st_pix_right[2 * o + 1] = (float)vR;
+    for (int c = 0; c < kGroup; ++c) {
+      keep[c] = t[c] >= 0 && stereo_keep(uL[c], vL[c], uR[c], vR[c], pix_thresh, disp_min);
+      const unsigned long long ballot = __ballot(keep[c]);
+      prefix[c] = __popcll(ballot & ((1ull << lane) - 1ull));
+      if (lane == 0) lds.wave_tot[c][wave] = __popcll(ballot);
     }
     __syncthreads();
-    if (threadIdx.x == 0) lds.running += chunk_total;
-    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < kGroup; ++c) {
+      int wave_base = 0, chunk_total = 0;
+#pragma unroll
+      for (int w = 0; w < kCompactBlock / 64; ++w) {
+        const int v = lds.wave_tot[c][w];
+        if (w < wave) wave_base += v;
+        chunk_total += v;
+      }
+      const int pos = running + wave_base + prefix[c];
+      running += chunk_total;
+      if (keep[c]) {
+        const size_t o = (size_t)(base + pos);
+        left_of[pos] = (uint32_t)q[c];
+        st_left[o] = q[c];
+        st_right[o] = t[c];
+        st_dist[o] = d[c];
+        // the pixels as float32, as they are stored: what the triangulation of the separate launch reads back
+        // (exact: they were float32 before they were widened)
+        const float fuL = (float)uL[c], fvL = (float)vL[c], fuR = (float)uR[c], fvR = (float)vR[c];
+        st_pix_left[2 * o + 0] = fuL;
+        st_pix_left[2 * o + 1] = fvL;
+        st_pix_right[2 * o + 0] = fuR;
+        st_pix_right[2 * o + 1] = fvR;
+        lds.pix[pos] = make_float4(fuL, fvL, fuR, fvR);
+      }
+    }
+    __syncthreads();     // the counts have been read before the next group overwrites them
   }
-  const int m = lds.running;
+  SLAMHIP_STAMP(3);
+  const int m = running;
   if (threadIdx.x == 0) st_count[f] = m;
-  // the survivors' points: the pixels come back from the arrays this workgroup has just written
+  // the survivors' points, every lane busy: the pixels (float32, as stored) come from LDS
   for (int i = threadIdx.x; i < m; i += kCompactBlock) {
     const size_t o = (size_t)(base + i);
+    const float4 px = lds.pix[i];
     double x[4];
-    dlt_null_vector(cam, (double)st_pix_left[2 * o], (double)st_pix_left[2 * o + 1],
-                    (double)st_pix_right[2 * o], (double)st_pix_right[2 * o + 1], x);
+    dlt_null_vector(cam, (double)px.x, (double)px.y, (double)px.z, (double)px.w, x);
     const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
     st_xyz[3 * o + 0] = x0 / x3;
     st_xyz[3 * o + 1] = x1 / x3;
     st_xyz[3 * o + 2] = x2 / x3;
   }
+  SLAMHIP_STAMP(4);
   // and their descriptor rows, in survivor order (as stereo_points_kernel)
   const int lw = W == 8 ? 3 : (W == 16 ? 4 : 5);
   const int cpr = W >> 2, lc = lw - 2;
@@ -315,6 +353,7 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
                                                      (uint32_t)(x >> 64) & mk(2), (uint32_t)(x >> 96) & mk(3));
     }
   }
+  SLAMHIP_STAMP(5);
 }
 
 // Second half of the stereo stage, over the compacted inliers only (every lane
@@ -536,6 +575,7 @@ __global__ __launch_bounds__(T) void temporal_tail_kernel(
     int32_t *__restrict__ tm_count, float *__restrict__ cx, float *__restrict__ cpl,
     float *__restrict__ cpr) {
   __shared__ TemporalTailLds<PIX, T, CAP> lds;
+  SLAMHIP_STAMP(8);
   const int p = blockIdx.x;
   const int qb = qbase[p], tb = tbase[p], ob = obase[p];
   const int nsort = qcnt[p];
@@ -564,7 +604,9 @@ __global__ __launch_bounds__(T) void temporal_tail_kernel(
     lds.train[i] = t;
     lds.sort.keys[0][i] = sort_key(d, i);
   }
+  SLAMHIP_STAMP(9);
   radix_sort_lds<T, CAP>(lds.sort, n);
+  SLAMHIP_STAMP(10);
   for (int r = threadIdx.x; r < n; r += T) {
     const uint32_t key = lds.sort.keys[0][r];
     const int q = (int)(key & kSortIdxMask);
@@ -589,6 +631,7 @@ __global__ __launch_bounds__(T) void temporal_tail_kernel(
       cpr[2 * o + c] = (float)pix_right[2 * (size_t)(tb + t) + c];
     }
   }
+  SLAMHIP_STAMP(11);
 }
 
 __device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
@@ -632,13 +675,16 @@ __device__ __forceinline__ int iterations_required(int count, int n, double log1
 template <bool kMax>
 __device__ __forceinline__ int block_scan(int v, int identity, int *wt, int &exclusive) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int t = __shfl_up(v, off, 64);
-    if (lane >= off) v = kMax ? max(v, t) : min(v, t);
-  }
-  int ex = __shfl_up(v, 1, 64);
-  if (lane == 0) ex = identity;
+  // within the wavefront through DPP, as sort_device.h's wave_inclusive_sum: lanes without a source take
+  // the identity
+  auto fold = [&](int t) { v = kMax ? max(v, t) : min(v, t); };
+  fold(__builtin_amdgcn_update_dpp(identity, v, 0x111, 0xF, 0xF, false));   // row_shr:1
+  fold(__builtin_amdgcn_update_dpp(identity, v, 0x112, 0xF, 0xF, false));   // row_shr:2
+  fold(__builtin_amdgcn_update_dpp(identity, v, 0x114, 0xF, 0xF, false));   // row_shr:4
+  fold(__builtin_amdgcn_update_dpp(identity, v, 0x118, 0xF, 0xF, false));   // row_shr:8
+  fold(__builtin_amdgcn_update_dpp(identity, v, 0x142, 0xA, 0xF, false));   // row_bcast:15 -> rows 1, 3
+  fold(__builtin_amdgcn_update_dpp(identity, v, 0x143, 0xC, 0xF, false));   // row_bcast:31 -> rows 2, 3
+  const int ex = __builtin_amdgcn_update_dpp(identity, v, 0x138, 0xF, 0xF, false);   // wave_shr:1 (lane 0: identity)
   if (lane == 63) wt[wave] = v;
   __syncthreads();
   int before = identity;
@@ -662,12 +708,13 @@ __device__ __forceinline__ int block_scan(int v, int identity, int *wt, int &exc
 // Updates the pair's state record and returns the lane of a new best
 // hypothesis of this round or -1 (same value in every thread).
 // `red` holds 4 + kBlock / 64 ints of LDS.
-__device__ int replay_round(int32_t *__restrict__ s, const int32_t *__restrict__ counts, int round,
+// `s` may be the pair's record in memory or a copy of it in LDS; `c` = counts[threadIdx.x], loaded
+// by the caller (which may have asked for it well before).
+__device__ int replay_round(int32_t *s, const int32_t *__restrict__ counts, const int c, int round,
                             int n, int n_iter_max, double log1mp, int *red) {
   const int i = (int)threadIdx.x;
   const int best0 = s[1], done0 = s[2], req0 = s[3];
-  const int g = round * kHypPerRound + i;
-  const int c = counts[i];                 // -1: no pose from this sample, -2: not generated
+  const int g = round * kHypPerRound + i;   // c: -1 = no pose from this sample, -2 = not generated
   if (i < 4) red[i] = (i == 1) ? -1 : (i == 2 ? 2147483647 : 0);  // reached, winner, requirement, domain
   int before;
   block_scan<true>(max(c, best0), best0, red + 4, before);
@@ -761,8 +808,8 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
     }
   } else {
     if (replay && !s[7])   // slots == 1; s[7]: same value in every thread, written by an earlier launch
-      winner = replay_round(s, counts + row * kHypPerRound, first_block - 1, n, prm.n_iter_max,
-                            log(1.0 - prm.p_success), red);
+      winner = replay_round(s, counts + row * kHypPerRound, counts[row * kHypPerRound + threadIdx.x],
+                            first_block - 1, n, prm.n_iter_max, log(1.0 - prm.p_success), red);
     if (threadIdx.x == 0) {
       sh[0] = s[7];
       sh[1] = winner;
@@ -1098,22 +1145,47 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
   __shared__ int sh[3];  // winner lane, have a best hypothesis, mask count
   __shared__ double best_rt[12];
   __shared__ RefineLds refine_lds;
+  SLAMHIP_STAMP(16);
   const int p = blockIdx.x;
   int32_t *s = info + 8 * (size_t)p;
   const int n = tm_count[p];
   __shared__ int red[4 + kBlock / 64];
+  // The pair's record stays in LDS while the blocks are replayed (a round trip through memory per
+  // block otherwise), and the loads that do not depend on the outcome are asked for up front: the next
+  // block's counts before the current one is replayed, this thread's first correspondences before any.
+  __shared__ int32_t state[8];
+  if (threadIdx.x < 8) state[threadIdx.x] = s[threadIdx.x];
+  const size_t base = (size_t)obase[p];
+  const float *X = cx + 3 * base, *mL = cpl + 2 * base, *mR = cpr + 2 * base;
+  constexpr int kAhead = 3;               // correspondences per thread fetched ahead (768 a pair)
+  float pre[kAhead][7];
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) {
+    const int i = (int)threadIdx.x + j * kBlock;
+    const size_t g = (size_t)(i < n ? i : 0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) pre[j][c] = n > 0 ? X[3 * g + c] : 0.0f;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) { pre[j][3 + c] = n > 0 ? mL[2 * g + c] : 0.0f; pre[j][5 + c] = n > 0 ? mR[2 * g + c] : 0.0f; }
+  }
   int winner = -1, winner_slot = 0;
   const double log1mp = log(1.0 - prm.p_success);
+  const int32_t *const my_counts = counts + (size_t)p * slots * kHypPerRound + threadIdx.x;
+  int c_next = my_counts[0];
+  __syncthreads();
   for (int k = 0; k < slots; ++k) {
-    if (s[7]) break;       // same value in every thread: written before the barrier below
-    const int w = replay_round(s, counts + ((size_t)p * slots + k) * kHypPerRound, first_block + k, n,
+    if (state[7]) break;   // same value in every thread: written before the barrier below
+    const int c = c_next;
+    if (k + 1 < slots) c_next = my_counts[(size_t)(k + 1) * kHypPerRound];
+    const int w = replay_round(state, counts + ((size_t)p * slots + k) * kHypPerRound, c, first_block + k, n,
                                prm.n_iter_max, log1mp, red);
     if (w >= 0) { winner = w; winner_slot = k; }
     __syncthreads();       // thread 0's state update is visible to the next pass
   }
+  SLAMHIP_STAMP(17);
   if (threadIdx.x == 0) {
     sh[0] = winner;
-    sh[1] = s[0] >= 0;
+    sh[1] = state[0] >= 0;
     sh[2] = 0;
   }
   __syncthreads();
@@ -1124,35 +1196,43 @@ __global__ __launch_bounds__(kBlock) void ransac_finish_kernel(
     pose_ransac[12 * (size_t)p + threadIdx.x] = v;
   }
   __syncthreads();
-  const size_t base = (size_t)obase[p];
-  const float *X = cx + 3 * base, *mL = cpl + 2 * base, *mR = cpr + 2 * base;
   double Rt[12], PL[12], PR[12];
   for (int i = 0; i < 12; ++i) Rt[i] = best_rt[i];
   make_projections(Rt, prm.cam, PL, PR);
   const double thr2 = threshold_squared(prm.thresh);
   const bool have = sh[1] != 0;
-  for (int i = threadIdx.x; i < n; i += kBlock) {
+  auto judge = [&](int i, float x, float y, float z, float ul, float vl, float ur, float vr) {
     bool in = false;
     if (have) {
-      const double Xd = (double)X[3 * (size_t)i], Yd = (double)X[3 * (size_t)i + 1],
-                   Zd = (double)X[3 * (size_t)i + 2];
-      in = inlier_one_camera(PL, Xd, Yd, Zd, (double)mL[2 * (size_t)i], (double)mL[2 * (size_t)i + 1],
-                             prm.thresh, thr2) &&
-           inlier_one_camera(PR, Xd, Yd, Zd, (double)mR[2 * (size_t)i], (double)mR[2 * (size_t)i + 1],
-                             prm.thresh, thr2);
+      const double Xd = (double)x, Yd = (double)y, Zd = (double)z;
+      in = inlier_one_camera(PL, Xd, Yd, Zd, (double)ul, (double)vl, prm.thresh, thr2) &&
+           inlier_one_camera(PR, Xd, Yd, Zd, (double)ur, (double)vr, prm.thresh, thr2);
     }
     tm_mask[base + i] = in ? 1 : 0;
     if (in) atomicAdd(&sh[2], 1);
+  };
+#pragma unroll
+  for (int j = 0; j < kAhead; ++j) {
+    const int i = (int)threadIdx.x + j * kBlock;
+    if (i < n) judge(i, pre[j][0], pre[j][1], pre[j][2], pre[j][3], pre[j][4], pre[j][5], pre[j][6]);
   }
+  for (int i = (int)threadIdx.x + kAhead * kBlock; i < n; i += kBlock)
+    judge(i, X[3 * (size_t)i], X[3 * (size_t)i + 1], X[3 * (size_t)i + 2], mL[2 * (size_t)i], mL[2 * (size_t)i + 1],
+          mR[2 * (size_t)i], mR[2 * (size_t)i + 1]);
   if (seg_end != nullptr) {
     const int last = (clear_after_last && p == (int)gridDim.x - 1) ? seg_end[p + 1] : seg_end[p];
     for (size_t i = base + n + threadIdx.x; i < (size_t)last; i += kBlock) tm_mask[i] = 0;
   }
   __syncthreads();
-  if (threadIdx.x == 0) { s[5] = n; s[6] = sh[2]; s[7] = 0; }
+  if (threadIdx.x < 8) {
+    const int i = threadIdx.x;
+    s[i] = i == 5 ? n : (i == 6 ? sh[2] : (i == 7 ? 0 : state[i]));
+  }
+  SLAMHIP_STAMP(18);
   if (REFINE)   // the mask rows this workgroup has written come back from memory behind the barrier above
     refine_problem<float>(X, mL, tm_mask + base, n, best_rt, intr, refine_iters, pose_refined + 12 * (size_t)p,
                           (double *)nullptr, refine_lds);
+  SLAMHIP_STAMP(19);
 }
 
 // A call with few pairs is bound by its dependent launches, not by arithmetic: it
@@ -1333,6 +1413,7 @@ struct Layout {
 
 constexpr int kInPlaceRows = 4096;   // features per image up to which the stereo matcher reads unpacked rows
 constexpr int kSmallCallFrames = 3;  // frames up to which a front-end call runs its stages as fused launches
+constexpr int kSmallCallRows = 4096; // ... and features per image
 
 Layout make_layout(const slamhip_frontend_args *a) {
   Layout L;
@@ -1465,7 +1546,11 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   // A call of a few frames runs its stages as fused launches (stereo_tail_kernel,
   // temporal_tail_kernel, refinement behind the RANSAC replay): same results, a shorter chain.
   const bool fused_sort = slamhip_internal::sort_choice() == 0 && a->max_left <= kFusedSortMax;
-  const bool small_call = slamhip_internal::g_small_call_fusion != 0 && F <= kSmallCallFrames && fused_sort;
+  // (up to 4096 features an image: measured per call of one pair, fused against separate launches,
+  // 300 features 73 / 86 us, 1500 77 / 85, 3000 103 / 108, 6000 157 / 148, 8000 185 / 174 -- with
+  // thousands of survivors the one workgroup a frame has in the fused stage is the longer chain)
+  const bool small_call = slamhip_internal::g_small_call_fusion != 0 && F <= kSmallCallFrames && fused_sort &&
+                          a->max_left <= kSmallCallRows;
   slamhip_internal::Knn2Splits unfolded = {nullptr, 1, 0};
   if (!a->stereo_cross_check) {
     rc = slamhip_internal::knn2(rowsL, a->n_left_total, rowsR,
@@ -1496,7 +1581,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   for (int i = 0; i < 12; ++i) { cam.PL[i] = a->P_left[i]; cam.PR[i] = a->P_right[i]; }
   const size_t raw_bytes = (size_t)(a->n_left_total - 1) * a->desc_stride + a->desc_bytes;
   if (small_call) {
-    auto k = a->max_left <= 2048 ? stereo_tail_kernel<2048> : stereo_tail_kernel<kFusedSortMax>;
+    auto k = a->max_left <= 2048 ? stereo_tail_kernel<2048> : stereo_tail_kernel<kSmallCallRows>;
     hipLaunchKernelGGL(k, dim3(Fs), dim3(kCompactBlock), 0, st, a->d_kp_left, a->d_kp_right, s_off_left,
                        s_off_right, idx2, dist2, unfolded.part, unfolded.splits, unfolded.rows,
                        a->pixel_thresh, a->disparity_min, s_st_count, a->d_st_left, a->d_st_right,
@@ -1551,7 +1636,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   if (small_call) {
     if (a->temporal_cross_check) unfolded = {nullptr, 1, 0};
     auto k = a->max_left <= 2048 ? temporal_tail_kernel<float, 1024, 2048>
-                                 : temporal_tail_kernel<float, 1024, kFusedSortMax>;
+                                 : temporal_tail_kernel<float, 1024, kSmallCallRows>;
     hipLaunchKernelGGL(k, dim3(F - 1), dim3(1024), 0, st, a->d_off_left, a->d_st_count, a->d_off_left + 1,
                        a->d_st_count + 1, a->d_off_left, tidx2, tdist2, unfolded.part, unfolded.splits,
                        unfolded.rows, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_tm_query,
@@ -1783,6 +1868,9 @@ int slamhip_verify_pairs(const slamhip_verify_args *a, void *stream) {
 
 }  // extern "C"
 
+#ifdef SLAMHIP_STAMPS
+extern "C" int slamhip_debug_stamps(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(g_stamps)); }
+#endif
 #ifdef SLAMHIP_DEBUG_SPARSE
 extern "C" int slamhip_debug_counters(unsigned long long *out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(slamhip_dev::g_dbg), 16); }
 #endif

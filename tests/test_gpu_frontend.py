@@ -697,7 +697,7 @@ def test_any_number_of_rounds_before_the_merged_tail_gives_the_same_results():
 
 
 @pytest.mark.parametrize("cross", [False, True])
-@pytest.mark.parametrize("F,nfeat,nbytes", [(2, (1200, 1600), 61), (3, (100, 2600), 61), (2, (2100, 5000), 32),
+@pytest.mark.parametrize("F,nfeat,nbytes", [(2, (1200, 1600), 61), (3, (100, 2600), 61), (2, (2100, 4000), 32),
                                             (3, (40, 700), 100)])
 def test_calls_of_a_few_frames_run_fused_launches_with_the_same_results(cross, F, nfeat, nbytes):
     """A front-end call of up to three frames (the frame-at-a-time use of the reference's own loop,
