@@ -84,6 +84,38 @@ class OnlinePair(FrontendResult):
         return rec[:12].reshape(3, 4).copy(), rec[12:].view(np.int32).copy()
 
 
+class OnlineRecords:
+    """The records of a sequence pushed frame by frame, on the host: frame(f) / pair(p) /
+    relative_Rts() / n_frames as on a FrontendResult, i.e. what db_adapter.replay_into_db,
+    save_records and save_relative_Rts take (the hand-over to TrackingDB.add_frame,
+    fill_database.py:231, and the `relative_Rts` file, :252-255).  `add(pair)` after every push
+    that returned a pair."""
+
+    def __init__(self, frame_cross_check: bool = False):
+        self.frame_cross_check = bool(frame_cross_check)
+        self._frames, self._pairs = [], []
+
+    def add(self, pair: "OnlinePair") -> None:
+        copy = lambda d: {k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in d.items()}
+        if not self._frames:
+            self._frames.append(copy(pair.frame(0)))      # the sequence's first frame
+        self._frames.append(copy(pair.frame(1)))
+        self._pairs.append(copy(pair.pair(0)))
+
+    @property
+    def n_frames(self) -> int:
+        return len(self._frames)
+
+    def frame(self, f: int) -> dict:
+        return self._frames[f]
+
+    def pair(self, p: int) -> dict:
+        return self._pairs[p]
+
+    def relative_Rts(self) -> np.ndarray:
+        return np.stack([p["Rt"] for p in self._pairs]) if self._pairs else np.zeros((0, 3, 4))
+
+
 class OnlineFrontend:
     """`frames_capacity`: how many frames of the first frame's size the device arrays hold
     before the last frame's rows are moved to the front (a dozen small copies); parameters

@@ -185,9 +185,11 @@ def test_sharded_run_two_ranks_equals_single_rank():
     assert sorted(results) == [(0, True), (1, True)], results
 
 
-def test_run_sequence_tool_from_feature_cache(tmp_path):
-    """tools/run_sequence.py end to end on a synthesised cache: the pickled poses
-    and the saved records equal what the front-end returns for the same frames."""
+@pytest.mark.parametrize("mode", [[], ["--online"]])
+def test_run_sequence_tool_from_feature_cache(tmp_path, mode):
+    """tools/run_sequence.py end to end on a synthesised cache, batched and one frame at a time
+    (--online): the pickled poses and the saved records equal what the front-end returns for the
+    same frames."""
     import pickle
     import subprocess
     import sys
@@ -197,7 +199,7 @@ def test_run_sequence_tool_from_feature_cache(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     feats, out = str(tmp_path / "features"), str(tmp_path / "out")
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_sequence.py"), "--features", feats,
-                        "--out", out, "--synthesize", "6"], capture_output=True, text=True, timeout=300)
+                        "--out", out, "--synthesize", "6"] + mode, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "5 relative poses" in r.stdout
     with open(os.path.join(out, "relative_Rts"), "rb") as fh:

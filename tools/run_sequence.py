@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Runs the batched front-end over a cached feature sequence and writes what the
+"""Runs the front-end (batched, or with --online one frame at a time) over a cached feature sequence and writes what the
 reference's pose-graph stage loads (run_slam.py:80-89): the relative poses and
 the per-frame link / match records.
 
@@ -35,6 +35,9 @@ def main(argv=None):
     ap.add_argument("--pix-thresh", type=float, default=4.0)
     ap.add_argument("--stereo-cross-check", action="store_true")   # as run_slam.py:34-35
     ap.add_argument("--frame-cross-check", action="store_true")
+    ap.add_argument("--online", action="store_true",
+                    help="one frame at a time (OnlineFrontend.push, the reference's own loop shape) instead of "
+                         "one batched call; single GPU; same results")
     args = ap.parse_args(argv)
 
     import torch
@@ -68,7 +71,20 @@ def main(argv=None):
                           stereo_cross_check=args.stereo_cross_check,
                           frame_cross_check=args.frame_cross_check)
     t0 = time.perf_counter()
-    res = sharding.run_sharded(fe, frames, rank, world, group)
+    if args.online:
+        if world > 1:
+            raise SystemExit("--online runs on one GPU")
+        from slam_amd.backend.tracking.online import OnlineFrontend, OnlineRecords
+        online = OnlineFrontend(cam, disparity_min=args.disp_min, pixel_thresh=args.pix_thresh, seed=0,
+                                stereo_cross_check=args.stereo_cross_check,
+                                frame_cross_check=args.frame_cross_check)
+        res = OnlineRecords(args.frame_cross_check)
+        for k in range(len(frames)):
+            pair = online.push(*frames[k])
+            if pair is not None:
+                res.add(pair)
+    else:
+        res = sharding.run_sharded(fe, frames, rank, world, group)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
