@@ -16,10 +16,13 @@ __device__ __forceinline__ void cross3(const double *a, const double *b, double 
 __device__ __forceinline__ double dot3(const double *a, const double *b) {
   return a[0] * b[0] + a[1] * b[1] + a[2] * b[2];
 }
+// (a reciprocal square root in place of a root and a division: the minimal solver is a chain of
+// some 2300 fp64 instructions per wavefront, a fifth of which were the divisions and roots of the
+// normalisations, the first depth and the fourth point's projection)
 __device__ __forceinline__ bool normalize3(double *a) {
-  const double n = sqrt(dot3(a, a));
-  if (!(n > 0.0)) return false;
-  const double inv = 1.0 / n;
+  const double n2 = dot3(a, a);
+  if (!(n2 > 0.0)) return false;
+  const double inv = rsqrt(n2);
   a[0] *= inv; a[1] *= inv; a[2] *= inv;
   return true;
 }
@@ -59,6 +62,7 @@ __device__ __forceinline__ bool p3p_lane(const double (&X)[4][3], const double (
     d23[c] = X[1][c] - X[2][c];
   }
   const double a12 = dot3(d12, d12), a13 = dot3(d13, d13), a23 = dot3(d23, d23);
+  const double sqrt_a12 = sqrt(a12);
   const double c12 = dot3(f[0], f[1]), c13 = dot3(f[0], f[2]), c23 = dot3(f[1], f[2]);
   double Fw[3][3];
   const bool world_ok = a12 > 0.0 && a13 > 0.0 && a23 > 0.0 && triangle_frame(X[0], X[1], X[2], Fw);
@@ -101,7 +105,7 @@ __device__ __forceinline__ bool p3p_lane(const double (&X)[4][3], const double (
       const double den = 1.0 + u * u - 2.0 * u * c12;
       if (!(den > 0.0)) continue;
       double d[3];
-      d[0] = sqrt(a12 / den);
+      d[0] = sqrt_a12 * rsqrt(den);
       d[1] = u * d[0];
       d[2] = v * d[0];
       // two Gauss-Newton steps on the three distance equations
@@ -137,7 +141,8 @@ __device__ __forceinline__ bool p3p_lane(const double (&X)[4][3], const double (
       double c4[3];
       for (int i = 0; i < 3; ++i)
         c4[i] = Rt[4 * i] * X[3][0] + Rt[4 * i + 1] * X[3][1] + Rt[4 * i + 2] * X[3][2] + Rt[4 * i + 3];
-      const double ex = c4[0] / c4[2] - nrm[3][0], ey = c4[1] / c4[2] - nrm[3][1];
+      const double iz = 1.0 / c4[2];
+      const double ex = c4[0] * iz - nrm[3][0], ey = c4[1] * iz - nrm[3][1];
       const double err = ex * ex + ey * ey;
       if (err < best_err) {
         best_err = err;
@@ -154,8 +159,9 @@ __device__ __forceinline__ void pixel_to_bearing(const Kinv &ki, double u, doubl
                                                  double (&nrm)[2]) {
   double b[3];
   for (int c = 0; c < 3; ++c) b[c] = ki.m[3 * c + 0] * u + ki.m[3 * c + 1] * v + ki.m[3 * c + 2];
-  nrm[0] = b[0] / b[2];
-  nrm[1] = b[1] / b[2];
+  const double ib = 1.0 / b[2];
+  nrm[0] = b[0] * ib;
+  nrm[1] = b[1] * ib;
   normalize3(b);
   for (int c = 0; c < 3; ++c) f[c] = b[c];
 }

@@ -17,9 +17,12 @@ SLAMHIP_HD double quartic_eval(double a, double b, double c, double d, double x)
 
 SLAMHIP_HD double quartic_polish(double a, double b, double c, double d, double x) {
   // Newton on x^4 + a x^3 + b x^2 + c x + d; a step is taken only while it is finite
-  // and does not increase |f|, so a (near-)double root is left where it is.
+  // and does not increase |f|, so a (near-)double root is left where it is.  Two steps: on
+  // the 1e6 polynomials of tools/quartic_check.hip one already reaches the worst error of
+  // three (1.35 x the root's own rounding sensitivity), and every step is a division in a
+  // chain that every wavefront of the minimal solver walks four times.
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < 2; ++it) {
     const double f = quartic_eval(a, b, c, d, x);
     const double df = fma(fma(fma(4.0, x, 3.0 * a), x, 2.0 * b), x, c);
     const double xn = x - f / df;
@@ -51,9 +54,9 @@ SLAMHIP_HD double cubic_largest_root(double A, double B, double C) {
     t = 2.0 * m * cos(acos(arg) * third);
   }
   double z = t - sh;
-  // Newton on the cubic itself
+  // one Newton step on the cubic itself (the same check shows no difference between none and three)
 #pragma unroll
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < 1; ++it) {
     const double f = fma(fma(z + A, z, B), z, C);
     const double df = fma(fma(3.0, z, 2.0 * A), z, B);
     const double zn = z - f / df;
