@@ -79,7 +79,12 @@ const char *slamhip_strerror(int code);
  * by pair, so that a pair's rows come into one L2 (1, the default), or use the plain grid (0);
  * same results; knob 13 = rounds of 256 hypotheses a long front-end call runs over all its pairs
  * before the rest of the iteration cap goes through the merged launch (1..3, default 2; set it before
- * sizing a workspace; identical results); knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
+ * sizing a workspace; identical results); knob 14 = front-end calls of up to three frames of up to 4096
+ * features run their stages as fused launches (1, the default: the matcher's train splits folded by
+ * the stage behind it, sort + filter + triangulation + gather in one launch per stage, the refinement
+ * behind the RANSAC replay) or as the launches of a long call (0); identical results; knob 15 =
+ * correspondences per one-wavefront block of the consensus count of such calls (0, the default: from
+ * the sizes, 32 for one pair; else an even number); identical results; knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
  * per SIMD (64-byte rows only; measured slower).  Process-global; not for use while other threads
  * are inside the library. */
 int slamhip_tune(int knob, int value);

@@ -233,21 +233,21 @@ class OnlineFrontend:
         NL, NR = pl + nl, pr + nr
         slot = self._slot                        # per-frame entry of the window's first frame
         where = b["where"]
-        at = lambda name, row: where[name][0] + row * where[name][1]
+        addr = lambda name, row: where[name][0] + row * where[name][1]      # device address of a row
         a = self._arguments()
         a.n_frames, a.n_left_total, a.n_right_total = F, NL, NR
         a.max_left, a.max_right = max(pl, nl), max(pr, nr)
         a.desc_bytes, a.desc_stride = D, D
-        a.d_kp_left, a.d_kp_right = at("kp_left", wl), at("kp_right", wr)
-        a.d_des_left, a.d_des_right = at("des_left", wl), at("des_right", wr)
+        a.d_kp_left, a.d_kp_right = addr("kp_left", wl), addr("kp_right", wr)
+        a.d_des_left, a.d_des_right = addr("des_left", wl), addr("des_right", wr)
         d_off = b["off"].data_ptr()
         a.d_off_left, a.d_off_right = d_off, d_off + 12
         a.first_pair = max(self.n_pushed - 1, 0)
         a.first_stereo_frame = 0 if first else 1
         for name in _OUTPUTS:
-            setattr(a, "d_" + name, at(name, wl))
+            setattr(a, "d_" + name, addr(name, wl))
         for name in ("st_count", "pose_ransac", "pose_refined", "ransac_info"):
-            setattr(a, "d_" + name, at(name, slot))
+            setattr(a, "d_" + name, addr(name, slot))
         need = lib.slamhip_frontend_workspace_bytes(C.byref(a))
         if need == 0:
             check(_lib.EUNSUPPORTED, "slamhip_frontend_workspace_bytes")

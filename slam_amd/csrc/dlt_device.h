@@ -4,6 +4,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// Floating-point contraction in this header is confined to what the source spells out (a product
+// and the sum it feeds in one expression, or an explicit fma): the functions here are inlined into
+// several kernels whose results are compared bit for bit, and the compiler's default for device
+// code (fuse whatever it finds once everything is inlined) makes that depend on the surroundings.
+#pragma clang fp contract(on)
 namespace slamhip_dev {
 
 struct CamPair {
@@ -165,3 +170,5 @@ __device__ __forceinline__ void dlt_null_vector(const CamPair &cam, double uL, d
 }
 
 }  // namespace slamhip_dev
+#pragma clang fp contract(fast)   // the compiler's default for device code, for whatever follows
+

@@ -4,6 +4,11 @@
 #include <hip/hip_runtime.h>
 #include "quartic.h"
 
+// Floating-point contraction in this header is confined to what the source spells out (a product
+// and the sum it feeds in one expression, or an explicit fma): the functions here are inlined into
+// several kernels whose results are compared bit for bit, and the compiler's default for device
+// code (fuse whatever it finds once everything is inlined) makes that depend on the surroundings.
+#pragma clang fp contract(on)
 namespace slamhip_dev {
 
 struct Kinv { double m[9]; };
@@ -167,3 +172,5 @@ __device__ __forceinline__ void pixel_to_bearing(const Kinv &ki, double u, doubl
 }
 
 }  // namespace slamhip_dev
+#pragma clang fp contract(fast)   // the compiler's default for device code, for whatever follows
+

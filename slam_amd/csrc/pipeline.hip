@@ -573,10 +573,13 @@ __global__ __launch_bounds__(T) void temporal_tail_kernel(
     const float *__restrict__ xyz, const PIX *__restrict__ pix_left, const PIX *__restrict__ pix_right,
     int32_t *__restrict__ tm_query, int32_t *__restrict__ tm_train, int32_t *__restrict__ tm_dist,
     int32_t *__restrict__ tm_count, float *__restrict__ cx, float *__restrict__ cpl,
-    float *__restrict__ cpr) {
+    float *__restrict__ cpr, int32_t *__restrict__ clear, int clear_per_pair) {
   __shared__ TemporalTailLds<PIX, T, CAP> lds;
   SLAMHIP_STAMP(8);
   const int p = blockIdx.x;
+  // the pair's slots of the RANSAC count table, for a counting launch that only adds (may be null)
+  if (clear != nullptr)
+    for (int i = threadIdx.x; i < clear_per_pair; i += T) clear[(size_t)p * clear_per_pair + i] = 0;
   const int qb = qbase[p], tb = tbase[p], ob = obase[p];
   const int nsort = qcnt[p];
   const int n = tcnt[p] > 0 ? nsort : 0;  // no train rows -> no matches
@@ -760,6 +763,44 @@ struct RansacParams {
   const long long *pair_ids;   // or, when not null: pair_ids[pair0 + p] is pair p's number in the whole job
 };
 
+// Hypothesis `it` of pair p of the launch: its four sample points (from the caller's table, or
+// drawn from the sampler keyed by the pair's number in the whole job, so that batching, chunking
+// and sharding over ranks do not change a pair's samples) and the pose the minimal solver gives
+// them.  X / mL: the pair's n correspondences.  One function for every launch that generates
+// hypotheses, so that they all generate the same ones.
+__device__ __forceinline__ bool sample_and_solve(const float *__restrict__ X, const float *__restrict__ mL, int n,
+                                                 const int32_t *__restrict__ samples, const RansacParams &prm,
+                                                 int p, int it, int (&s4)[4], double (&Rt)[12]) {
+  const unsigned long long gp = (unsigned long long)(prm.pair0 + p);
+  if (samples != nullptr) {
+    const int32_t *sp = samples + ((size_t)gp * prm.n_iter_max + it) * 4;
+    for (int k = 0; k < 4; ++k) s4[k] = min(max(sp[k], 0), n - 1);
+  } else {
+    const unsigned long long sp_ = (unsigned long long)(prm.pair_ids != nullptr ? prm.pair_ids[prm.pair0 + p]
+                                                                                 : prm.seq0 + prm.pair0 + p);
+    unsigned long long r = splitmix64(prm.seed ^ (sp_ << 32) ^ (unsigned long long)it);
+    for (int k = 0; k < 4; ++k) {
+      int c = 0;
+      for (int tries = 0; tries < 64; ++tries) {
+        r = splitmix64(r);
+        c = (int)(((r >> 32) * (unsigned long long)n) >> 32);
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup |= (s4[j] == c);
+        if (!dup) break;
+      }
+      s4[k] = c;
+    }
+  }
+  double Xs[4][3], f[4][3], nrm4[2];
+  for (int k = 0; k < 4; ++k) {
+    for (int c = 0; c < 3; ++c) Xs[k][c] = (double)X[3 * (size_t)s4[k] + c];
+    double nk[2];
+    pixel_to_bearing(prm.kinv, (double)mL[2 * (size_t)s4[k]], (double)mL[2 * (size_t)s4[k] + 1], f[k], nk);
+    if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
+  }
+  return p3p_lane(Xs, f, nrm4, Rt);
+}
+
 // grid (pairs, slots).  A launch covers `slots` consecutive blocks of kHypPerRound
 // hypotheses per pair, starting at block `first_block`: 1 in the round scheme; all of them
 // (first_block 0, no replay in between) when a call has so few pairs that launches, not
@@ -840,38 +881,9 @@ __attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void 
   if (active) {
     const float *X = cx + 3 * (size_t)obase[p];
     const float *mL = cpl + 2 * (size_t)obase[p];
-    const unsigned long long gp = (unsigned long long)(prm.pair0 + p);
     int s4[4];
-    if (samples != nullptr) {
-      const int32_t *sp = samples + ((size_t)gp * prm.n_iter_max + it) * 4;
-      for (int k = 0; k < 4; ++k) s4[k] = min(max(sp[k], 0), n - 1);
-    } else {
-      // keyed by the pair's index in the whole job, so that batching, chunking and
-      // sharding over ranks do not change a pair's samples
-      const unsigned long long sp_ = (unsigned long long)(prm.pair_ids != nullptr ? prm.pair_ids[prm.pair0 + p]
-                                                                                   : prm.seq0 + prm.pair0 + p);
-      unsigned long long r = splitmix64(prm.seed ^ (sp_ << 32) ^ (unsigned long long)it);
-      for (int k = 0; k < 4; ++k) {
-        int c = 0;
-        for (int tries = 0; tries < 64; ++tries) {
-          r = splitmix64(r);
-          c = (int)(((r >> 32) * (unsigned long long)n) >> 32);
-          bool dup = false;
-          for (int j = 0; j < k; ++j) dup |= (s4[j] == c);
-          if (!dup) break;
-        }
-        s4[k] = c;
-      }
-    }
-    double Xs[4][3], f[4][3], nrm4[2], Rt[12];
-    for (int k = 0; k < 4; ++k) {
-      for (int c = 0; c < 3; ++c) Xs[k][c] = (double)X[3 * (size_t)s4[k] + c];
-      double nk[2];
-      pixel_to_bearing(prm.kinv, (double)mL[2 * (size_t)s4[k]], (double)mL[2 * (size_t)s4[k] + 1],
-                       f[k], nk);
-      if (k == 3) { nrm4[0] = nk[0]; nrm4[1] = nk[1]; }
-    }
-    valid = p3p_lane(Xs, f, nrm4, Rt);
+    double Rt[12];
+    valid = sample_and_solve(X, mL, n, samples, prm, p, it, s4, Rt);
     if (valid) {
       for (int i = 0; i < 12; ++i) rt[(row * 12 + i) * kHypPerRound + threadIdx.x] = Rt[i];
       if (hyp32 != nullptr) {
@@ -1124,6 +1136,93 @@ void ransac_count_list_rectified_kernel(SLAMHIP_COUNT_ARGS, const int32_t *__res
   ransac_count_list_body<2>(SLAMHIP_COUNT_PASS, list);
 }
 
+// A call of a pair or two (the single pass over every hypothesis of the cap, see below) waits for
+// two chains in a row: the solve launch's (sample, minimal solver: the longest chain of arithmetic
+// in the call) and the counting launch's.  Here every counting wavefront -- 64 hypotheses x one
+// span of correspondences -- solves its own 64 hypotheses first, with the function the solve
+// launch uses, and counts them straight from registers: one launch and no pose / fp32-image tables
+// in between, at the price of every span's wavefront solving the same hypotheses again, which an
+// otherwise idle chip does not notice.  The wavefront of span 0 also writes the poses the finishing
+// launch picks the winner from; the block (span 0, group 0) writes the pair's start state.
+// The counts are added atomically into slots that are zero at launch (cleared by the launch in
+// front, temporal_tail_kernel): a hypothesis without a pose, or beyond the cap, keeps 0 where the
+// solve launch notes -1 / -2 -- the replay treats all three alike (none can exceed the best so
+// far, and the cap bounds the loop separately).  Rectified pairs with the fp32 screen only.
+// grid (spans, slots * kHypPerRound / 64, pairs), one wavefront per block.
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(SLAMHIP_P3P_WAVES, SLAMHIP_P3P_WAVES))) void ransac_solve_count_kernel(
+    int slots, const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
+    const float *__restrict__ cx, const float *__restrict__ cpl, const float *__restrict__ cpr,
+    const int32_t *__restrict__ samples, RansacParams prm, double *__restrict__ rt,
+    int32_t *__restrict__ counts, double *__restrict__ pose_ransac, int32_t *__restrict__ info,
+    int span_points) {
+  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
+  const int span = blockIdx.x, gy = blockIdx.y, p = blockIdx.z;
+  const int slot = gy / (kHypPerRound / 64), hyp_group = gy % (kHypPerRound / 64);
+  const size_t row = (size_t)p * slots + slot;
+  const int n = tm_count[p];
+  const int skip = (n >= 4 && n >= prm.min_points) ? 0 : 1;
+  if (span == 0 && gy == 0) {
+    int32_t *s = info + 8 * (size_t)p;
+    if (threadIdx.x == 0) {
+      s[0] = -1; s[1] = 0; s[2] = 0; s[3] = prm.n_iter_max; s[4] = 0; s[5] = n; s[6] = 0;
+      s[7] = skip;
+    }
+    if (threadIdx.x < 12) pose_ransac[12 * (size_t)p + threadIdx.x] = (threadIdx.x % 5 == 0) ? 1.0 : 0.0;  // [I|0]
+  }
+  const int span0 = span * span_points;
+  if (skip || span0 >= n) return;
+  const int span1 = min(n, span0 + span_points);
+  const int hyp = hyp_group * 64 + (int)threadIdx.x;
+  const int it = slot * kHypPerRound + hyp;
+  const size_t base0 = (size_t)obase[p];
+  double Rt[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) Rt[i] = 0.0;
+  bool valid = false;
+  if (it < prm.n_iter_max) {
+    int s4[4];
+    valid = sample_and_solve(cx + 3 * base0, cpl + 2 * base0, n, samples, prm, p, it, s4, Rt);
+    if (!valid) {
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Rt[i] = 0.0;
+    }
+  }
+  if (valid && span == 0)
+    for (int i = 0; i < 12; ++i) rt[(row * 12 + i) * kHypPerRound + hyp] = Rt[i];
+  if (!__any(valid)) return;
+  Hyp32 h32;
+  {
+    double PL[12], PR[12];
+    make_projections(Rt, prm.cam, PL, PR);
+    make_hyp32(PL, PR, h32);
+  }
+  const double thr2 = threshold_squared(prm.thresh);
+  float *ldsf = reinterpret_cast<float *>(lds);
+  int c = 0;
+  for (int p0 = span0; p0 < span1; p0 += kPtsPerChunk) {
+    const size_t base = base0 + p0;
+    const int cnt = min(kPtsPerChunk, span1 - p0);
+    if (p0 != span0) __syncthreads();
+    unsigned umax = 0u, s2max = 0u;
+    for (int j = threadIdx.x; 2 * j < cnt; j += 64) {
+      const size_t a = base + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
+      stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b, umax, s2max);
+    }
+    const Screen32 sc = make_screen(h32, wave_max_u32(umax), (float)prm.thresh, (float)thr2);
+    __syncthreads();
+    if (valid) {
+      auto exact = [&](const float *f) {
+        double PL_[12], PR_[12];
+        make_projections(Rt, prm.cam, PL_, PR_);
+        return inlier_exact_staged<true>(f, PL_, PR_, prm.thresh, thr2);
+      };
+      c += count_chunk_inliers_screened<true>(ldsf, cnt, h32, sc, thr2, exact);
+    }
+  }
+  if (valid && c) atomicAdd(counts + row * kHypPerRound + hyp, c);
+}
+
 // Replays the hypothesis blocks not replayed yet (the last round's one, or all
 // `slots` of a single-pass call, in order), then writes the winner's mask, its
 // count and the final info record.  `first_block` = index of the first of them.
@@ -1244,6 +1343,7 @@ constexpr int kPairsPerXcdDeal = 64;     // pairs from which the counting launch
 constexpr int kTailGrid = 4096;         // wavefronts of the merged tail's counting launch: 4 per SIMD
 constexpr int kSinglePassPairs = 64;    // measured break-even against the adaptive rounds at ~40 % inliers
 constexpr int kSmallCallBlocks = 2048;  // one-wavefront blocks the consensus count of a call of a few pairs aims at
+constexpr int kFusedSolveCountPairs = 2;   // pairs up to which the counting launch solves its own hypotheses
 
 int single_pass_slots(int n_pairs, int n_iter_max) {
   const int slots = slamhip_ceil_div(n_iter_max > 0 ? n_iter_max : 1, kHypPerRound);
@@ -1299,6 +1399,33 @@ size_t ransac_workspace_bytes(int n_pairs, int n_iter_max, bool merge_tail = fal
 
 // RANSAC for pairs [0, n_pairs) described by obase / tm_count; `prm.pair0` is
 // the first pair's index for sampling.  max_points bounds tm_count.
+// Correspondences per one-wavefront counting block of a single-pass call (see run_pair_ransac).
+int small_call_span(int np, int groups, int max_points) {
+  const long long work = (long long)np * groups * (max_points > 0 ? max_points : 1);
+  int sp = (int)((work / kSmallCallBlocks + 31) / 32 * 32);
+  if (slamhip_internal::g_small_call_span > 0) sp = slamhip_internal::g_small_call_span;
+  if (sp < 32) sp = 32;
+  return sp < kPtsPerChunk ? sp : kPtsPerChunk;
+}
+
+// Whether a call of n_pairs pairs may solve its hypotheses inside the counting launch
+// (ransac_solve_count_kernel): the single pass, the fp32 screen of a rectified pair, and the knob.
+bool fused_solve_count_applies(int n_pairs, const RansacParams &prm) {
+  return slamhip_internal::g_small_call_fusion != 0 && n_pairs <= kFusedSolveCountPairs &&
+         single_pass_slots(n_pairs, prm.n_iter_max) > 1 &&
+         screening_mode(slamhip_internal::g_ransac_screen, prm.cam.K, prm.cam.MR, prm.thresh) == 2 &&
+         slamhip_internal::g_ransac_screen != 3;
+}
+
+// The count table of a single-pass call of n_pairs pairs in its workspace, and its length in
+// entries (for the launch that clears it ahead of ransac_solve_count_kernel).
+int32_t *single_pass_counts(void *ws, int n_pairs, int n_iter_max, size_t *entries) {
+  const int slots = single_pass_slots(n_pairs, n_iter_max);
+  const RansacTables T = ransac_tables((size_t)n_pairs * slots, 0);
+  *entries = (size_t)n_pairs * slots * kHypPerRound;
+  return (int32_t *)((uintptr_t)ws + T.counts);
+}
+
 // What the finishing launch does beyond the replay and the mask (ransac_finish_kernel).
 struct FinishExtras {
   const int32_t *seg_end = nullptr;   // per pair: one past its last mask row; rows behind the matches are cleared
@@ -1307,6 +1434,8 @@ struct FinishExtras {
   Intr intr;                          // ... with these intrinsics,
   int refine_iters = 0;               // this pass limit,
   double *pose_refined = nullptr;     // into this array (12 doubles a pair)
+  bool counts_cleared = false;        // the single pass' count table (single_pass_counts) is zero: the launch
+                                      // in front has cleared it, and hypotheses may be solved where they are counted
 };
 
 int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *cx, const float *cpl,
@@ -1342,6 +1471,15 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
     auto count = sparse ? ransac_count_rectified_sparse_kernel
                  : mode == 2 ? ransac_count_rectified_kernel
                  : mode == 1 ? ransac_count_screened_kernel : ransac_count_fp64_kernel;
+    if (fx.counts_cleared && fused_solve_count_applies(n_pairs, prm) && !sparse) {
+      // (np == n_pairs: such a call is one group)
+      const int groups = slots * (kHypPerRound / 64);
+      const int span_points = small_call_span(np, groups, max_points);
+      const int spans = slamhip_ceil_div(max_points > 0 ? max_points : 1, span_points);
+      hipLaunchKernelGGL(ransac_solve_count_kernel, dim3(spans, groups, np), dim3(64), 0, st, slots, obase + g0,
+                         tm_count + g0, cx, cpl, cpr, samples, prm, rt, counts, pose_ransac + 12 * (size_t)g0,
+                         info + 8 * (size_t)g0, span_points);
+    } else
     for (int r = 0; r < rounds; ++r) {
       hipLaunchKernelGGL(ransac_solve_kernel, dim3(np, slots), dim3(kBlock), 0, st, r, slots, r > 0 ? 1 : 0, 1,
                          obase + g0, tm_count + g0, cx, cpl, samples, prm, rt, counts,
@@ -1358,13 +1496,7 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       // 128 correspondences: there a block takes fewer, down to 32, while the launch stays within
       // some two thousand blocks.
       int span_points = per_span * kPtsPerChunk;
-      if (slots > 1 && slamhip_internal::g_small_call_fusion) {
-        const long long work = (long long)np * groups * (max_points > 0 ? max_points : 1);
-        int sp = (int)((work / kSmallCallBlocks + 31) / 32 * 32);
-        if (slamhip_internal::g_small_call_span > 0) sp = slamhip_internal::g_small_call_span;
-        if (sp < 32) sp = 32;
-        if (sp < span_points) span_points = sp;
-      }
+      if (slots > 1 && slamhip_internal::g_small_call_fusion) span_points = min(span_points, small_call_span(np, groups, max_points));
       const int spans = slamhip_ceil_div(max_points > 0 ? max_points : 1, span_points);
       const dim3 cgrid = by_pair ? dim3((np + 7) / 8 * 8, spans, groups) : dim3(spans, groups, np);
       hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
@@ -1610,6 +1742,24 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   if (F < 2) return SLAMHIP_OK;
 
   // ---- temporal stage: pair p = frames (p, p+1)
+  RansacParams prm;
+  for (int i = 0; i < 9; ++i) prm.cam.K[i] = a->K[i];
+  for (int i = 0; i < 12; ++i) prm.cam.MR[i] = a->M_right[i];
+  if (!invert3x3(a->K, prm.kinv.m)) return SLAMHIP_EINVAL;
+  prm.thresh = a->ransac_thresh;
+  prm.p_success = a->p_success;
+  prm.n_iter_max = a->n_iter_max;
+  prm.min_points = 4;
+  prm.seed = a->seed;
+  prm.pair0 = 0;
+  prm.seq0 = a->first_pair;
+  prm.pair_ids = nullptr;
+  // a call of a pair or two solves its hypotheses inside the counting launch, which only adds to its
+  // count table: the temporal tail clears the table on its way
+  size_t clear_entries = 0;
+  int32_t *clear = nullptr;
+  if (small_call && fused_solve_count_applies(F - 1, prm))
+    clear = single_pass_counts((void *)(base + L.ransac), F - 1, prm.n_iter_max, &clear_entries);
   if (!a->temporal_cross_check) {
     rc = slamhip_internal::knn2((const uint8_t *)a->d_st_desc, a->n_left_total,
                                 (const uint8_t *)a->d_st_desc, a->n_left_total, a->desc_bytes, W * 4,
@@ -1640,7 +1790,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
     hipLaunchKernelGGL(k, dim3(F - 1), dim3(1024), 0, st, a->d_off_left, a->d_st_count, a->d_off_left + 1,
                        a->d_st_count + 1, a->d_off_left, tidx2, tdist2, unfolded.part, unfolded.splits,
                        unfolded.rows, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_tm_query,
-                       a->d_tm_train, a->d_tm_dist, tcount, cx, cpl, cpr);
+                       a->d_tm_train, a->d_tm_dist, tcount, cx, cpl, cpr, clear, (int)(clear_entries / (size_t)(F - 1)));
   } else if (fused_sort) {
     // many short pairs: 256 threads a block; few long ones: 1024
     auto k = a->max_left <= 2048 ? temporal_sort_gather_kernel<float, 256, 2048>
@@ -1661,18 +1811,6 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   }
   SLAMHIP_CHECK_LAUNCH();
 
-  RansacParams prm;
-  for (int i = 0; i < 9; ++i) prm.cam.K[i] = a->K[i];
-  for (int i = 0; i < 12; ++i) prm.cam.MR[i] = a->M_right[i];
-  if (!invert3x3(a->K, prm.kinv.m)) return SLAMHIP_EINVAL;
-  prm.thresh = a->ransac_thresh;
-  prm.p_success = a->p_success;
-  prm.n_iter_max = a->n_iter_max;
-  prm.min_points = 4;
-  prm.seed = a->seed;
-  prm.pair0 = 0;
-  prm.seq0 = a->first_pair;
-  prm.pair_ids = nullptr;
   // the finishing launch leaves no mask row of the call unwritten (the caller's array needs no fill)
   // and, in a call of a few frames, goes on to refine the winner
   FinishExtras fx;
@@ -1682,6 +1820,7 @@ int slamhip_frontend_batch(const slamhip_frontend_args *a, void *stream) {
   for (int i = 0; i < 9; ++i) fx.intr.K[i] = a->K[i];
   fx.refine_iters = a->refine_iters;
   fx.pose_refined = a->d_pose_refined;
+  fx.counts_cleared = clear != nullptr;
   rc = run_pair_ransac(a->d_off_left, tcount, cx, cpl, cpr, a->d_samples, prm, F - 1, a->max_left,
                        a->d_pose_ransac, a->d_tm_mask, a->d_ransac_info, (void *)(base + L.ransac), st,
                        /*merge_tail=*/true, /*mostly_unrelated=*/false, fx);

@@ -7,6 +7,11 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 
+// Floating-point contraction in this header is confined to what the source spells out (a product
+// and the sum it feeds in one expression, or an explicit fma): the functions here are inlined into
+// several kernels whose results are compared bit for bit, and the compiler's default for device
+// code (fuse whatever it finds once everything is inlined) makes that depend on the surroundings.
+#pragma clang fp contract(on)
 namespace slamhip_dev {
 
 #define SLAMHIP_HD __host__ __device__ __forceinline__
@@ -147,3 +152,5 @@ SLAMHIP_HD int quartic_real_roots_closed(const double (&q)[5], double (&roots)[4
 }
 
 }  // namespace slamhip_dev
+#pragma clang fp contract(fast)   // the compiler's default for device code, for whatever follows
+

@@ -6,6 +6,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Floating-point contraction in this header is confined to what the source spells out (a product
+// and the sum it feeds in one expression, or an explicit fma): the functions here are inlined into
+// several kernels whose results are compared bit for bit, and the compiler's default for device
+// code (fuse whatever it finds once everything is inlined) makes that depend on the surroundings.
+#pragma clang fp contract(on)
 namespace slamhip_dev {
 
 constexpr int kRefThreads = 256;
@@ -276,3 +281,5 @@ __device__ __forceinline__ void refine_problem(const PT *__restrict__ pts, const
 }
 
 }  // namespace slamhip_dev
+#pragma clang fp contract(fast)   // the compiler's default for device code, for whatever follows
+
