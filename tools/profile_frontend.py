@@ -20,6 +20,10 @@ fe = TrackingFrontend(cam)
 if os.environ.get("SLAMHIP_PROFILE_VARIANT"):          # matcher kernel variant forced (tune knob 0)
     from slam_amd import _lib
     _lib.lib.slamhip_tune(0, int(os.environ["SLAMHIP_PROFILE_VARIANT"]))
+for kv in os.environ.get("SLAMHIP_PROFILE_TUNE", "").split():     # knob=value pairs for slamhip_tune
+    from slam_amd import _lib
+    k, v = kv.split("=")
+    assert _lib.lib.slamhip_tune(int(k), int(v)) == 0
 inp = fe.upload(frames)
 for _ in range(3):
     fe.run(inp)
