@@ -784,6 +784,14 @@ def test_pushing_frames_one_at_a_time_equals_the_batched_call(cross):
         np.testing.assert_array_equal(Rt, want.pair(k - 1)["Rt"])
         assert info[5] == want.pair(k - 1)["n_matches"]
     assert sum(want.pair(p)["mask"].sum() for p in range(F - 1)) > 100
+    # the library refuses a first stereo frame outside the call's frames
+    import ctypes as C
+    from slam_amd import _lib
+    args = want.args
+    for bad in (-1, F):
+        args.first_stereo_frame = bad
+        assert _lib.lib.slamhip_frontend_batch(C.byref(args), torch.cuda.current_stream().cuda_stream) == _lib.EINVAL
+    args.first_stereo_frame = 0
     # a second sequence through the same object
     online.reset()
     assert online.push(*frames[1]) is None
