@@ -66,9 +66,9 @@ OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
 # Matrix-core matcher: one multiply-add per descriptor bit; the instruction stream pads rows to
 # 8 / 16 / 32 dwords.  Peak: MI355X block-scaled FP4 MFMA, dense (no sparsity).
 MFMA_PEAK_FLOPS = 10.0e15
-# HBM-side bytes per matrix-core top-2 launch, same recipe (profiles/r2/pmc_matcher8k_mfma.txt):
-# FETCH_SIZE 2276 KB x2 + WRITE_SIZE 1024 KB.
-PMC_TRAFFIC_BYTES_MFMA = (2276 * 2 + 1024) * 1024
+# HBM-side bytes per matrix-core top-2 launch, same recipe (profiles/r3/pmc_matcher8k.txt, final build:
+# FETCH_SIZE 2274 KB x2 + WRITE_SIZE 1024 KB; profiles/r2/pmc_matcher8k_mfma.txt had 2276).
+PMC_TRAFFIC_BYTES_MFMA = (2274 * 2 + 1024) * 1024
 
 
 def flop_per_compare(desc_bytes, issued=False):
@@ -98,7 +98,7 @@ def matcher_roofline(mfma, compares, kernel_s, n_launch, desc_bytes=DESC_BYTES):
                                "the matrix cores: rows are zero padded to 64 bytes",
                 "kernel_us": kernel_s * 1e6, "launches_timed": n_launch, **hbm,
                 "traffic": PMC_TRAFFIC_BYTES_MFMA,
-                "traffic_source": "profiles/r2/pmc_matcher8k_mfma.txt (separate rocprofv3 --pmc passes of "
+                "traffic_source": "profiles/r3/pmc_matcher8k.txt (separate rocprofv3 --pmc passes of "
                                   "the same call, not read in this run): FETCH_SIZE x2 + WRITE_SIZE; "
                                   "includes the 1 MB of split results the kernel writes for the merge"}
     achieved = compares * OPS_PER_COMPARE / kernel_s
