@@ -186,18 +186,19 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_sort_compact_kernel(
 // fill_database.py:140) is a chain of dependent launches of one or a few workgroups each, and
 // every launch in the chain costs some 3.5 us before it does anything.  For such calls the
 // whole stereo stage behind the matcher is ONE launch, one workgroup per frame: fold of the
-// matcher's train splits (its merge launch is left out), sort by distance, filter and
-// compaction as in stereo_sort_compact_kernel, then what stereo_points_kernel does for the
-// survivors.  The sorted order, the matches' train rows and the survivors' left rows stay in
-// LDS instead of going through memory between launches.  Same results as the separate launches.
+// matcher's train splits (its merge launch is left out), the row / disparity filter, the sort
+// by distance of the SURVIVORS only (compacted in left-row order first: sorting after the filter
+// then gives the order that filtering the sorted matches gives, for two fifths of the keys), then what
+// stereo_points_kernel does for them.  The survivors' right rows, pixels and sorted order stay
+// in LDS instead of going through memory between launches.  Same results as the separate launches.
 //   part != nullptr: part[split * part_rows + off_left[f] + i] holds the (best, second best) key
 //   of left row i within train split `split` (key = distance << 21 | right row, 0xFFFFFFFF =
 //   none); else the folded result is in idx2 / dist2.
 template <int CAP>
 struct StereoTailLds {
   RadixSortLds<kCompactBlock, CAP> sort;
-  int32_t train[CAP];
-  float4 pix[CAP];                       // survivors' (uL, vL, uR, vR), in survivor order
+  int32_t train[CAP];                    // survivors' right rows, by left row
+  float4 pix[CAP];                       // survivors' (uL, vL, uR, vR), by left row
   int wave_tot[2][kCompactBlock / 64];
 };
 template <int CAP>
@@ -219,61 +220,48 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
     if (threadIdx.x == 0) st_count[f] = 0;
     return;
   }
-  for (int i = threadIdx.x; i < nq; i += kCompactBlock) {
-    int t, d;
-    if (part != nullptr) {
-      uint32_t best = 0xFFFFFFFFu;           // keys are unique: the smallest is (closest, lowest right row)
-      for (int s0 = 0; s0 < splits; s0 += 16) {   // sixteen loads in flight (the matcher's usual split count)
-        uint32_t k[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) k[j] = part[(size_t)min(s0 + j, splits - 1) * part_rows + base + i].x;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) best = min(best, k[j]);
-      }
-      t = best == 0xFFFFFFFFu ? -1 : (int)(best & kSortIdxMask);
-      d = best == 0xFFFFFFFFu ? -1 : (int)(best >> kSortKeyShift);
-    } else {
-      t = idx2[2 * (size_t)(base + i)];
-      d = dist2[2 * (size_t)(base + i)];
-    }
-    lds.train[i] = t;
-    lds.sort.keys[0][i] = sort_key(d, i);
-  }
-  SLAMHIP_STAMP(1);
-  radix_sort_lds<kCompactBlock, CAP>(lds.sort, nq);
-  SLAMHIP_STAMP(2);
-  uint32_t *const left_of = lds.sort.keys[1];    // survivor -> left row, once the sort is done with the array
-  // Filter, compaction and triangulation, two chunks of kCompactBlock sorted matches at a time: the
-  // matches and pixels of both chunks are fetched and judged first (their loads in flight together),
-  // one barrier makes the wavefronts' survivor counts known, and every survivor is then written to
-  // its place; its pixels also go to LDS, for the triangulation behind the loop.
+  // Every left row's match first -- fold of the train splits -- and its verdict; the survivors' keys
+  // go into LDS in left-row order (the radix passes below sort by the distance field alone and
+  // leave equal distances in the order they start in), their right rows and pixels beside them,
+  // indexed by the left row.  Two chunks of kCompactBlock rows are judged before the one barrier
+  // that makes the wavefronts' survivor counts known.
   constexpr int kGroup = 2;
   int running = 0;
-  for (int chunk0 = 0; chunk0 < nq; chunk0 += kGroup * kCompactBlock) {
+  for (int i0 = 0; i0 < nq; i0 += kGroup * kCompactBlock) {
     bool keep[kGroup];
-    int q[kGroup], t[kGroup], d[kGroup], prefix[kGroup];
-    double uL[kGroup], vL[kGroup], uR[kGroup], vR[kGroup];
+    int prefix[kGroup], dist[kGroup];
 #pragma unroll
     for (int c = 0; c < kGroup; ++c) {
-      const int r = chunk0 + c * kCompactBlock + (int)threadIdx.x;
-      keep[c] = false; q[c] = 0; t[c] = -1; d[c] = -1;
-      uL[c] = vL[c] = uR[c] = vR[c] = 0.0;
-      if (r < nq) {
-        const uint32_t key = lds.sort.keys[0][r];
-        q[c] = (int)(key & kSortIdxMask);
-        t[c] = lds.train[q[c]];
-        d[c] = (int)(key >> kSortKeyShift);
-        if (t[c] >= 0) {
-          uL[c] = (double)kp_left[2 * (size_t)(base + q[c])];
-          vL[c] = (double)kp_left[2 * (size_t)(base + q[c]) + 1];
-          uR[c] = (double)kp_right[2 * (size_t)(rbase + t[c])];
-          vR[c] = (double)kp_right[2 * (size_t)(rbase + t[c]) + 1];
+      const int i = i0 + c * kCompactBlock + (int)threadIdx.x;
+      int t = -1, d = -1;
+      if (i < nq) {
+        if (part != nullptr) {
+          uint32_t best = 0xFFFFFFFFu;           // keys are unique: the smallest is (closest, lowest right row)
+          for (int s0 = 0; s0 < splits; s0 += 16) {   // sixteen loads in flight (the matcher's usual split count)
+            uint32_t k[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) k[j] = part[(size_t)min(s0 + j, splits - 1) * part_rows + base + i].x;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) best = min(best, k[j]);
+          }
+          t = best == 0xFFFFFFFFu ? -1 : (int)(best & kSortIdxMask);
+          d = best == 0xFFFFFFFFu ? -1 : (int)(best >> kSortKeyShift);
+        } else {
+          t = idx2[2 * (size_t)(base + i)];
+          d = dist2[2 * (size_t)(base + i)];
         }
       }
-    }
-#pragma unroll
-    for (int c = 0; c < kGroup; ++c) {
-      keep[c] = t[c] >= 0 && stereo_keep(uL[c], vL[c], uR[c], vR[c], pix_thresh, disp_min);
+      keep[c] = false;
+      dist[c] = d;
+      if (t >= 0) {
+        const float4 px = make_float4(kp_left[2 * (size_t)(base + i)], kp_left[2 * (size_t)(base + i) + 1],
+                                      kp_right[2 * (size_t)(rbase + t)], kp_right[2 * (size_t)(rbase + t) + 1]);
+        keep[c] = stereo_keep((double)px.x, (double)px.y, (double)px.z, (double)px.w, pix_thresh, disp_min);
+        if (keep[c]) {
+          lds.train[i] = t;
+          lds.pix[i] = px;
+        }
+      }
       const unsigned long long ballot = __ballot(keep[c]);
       prefix[c] = __popcll(ballot & ((1ull << lane) - 1ull));
       if (lane == 0) lds.wave_tot[c][wave] = __popcll(ballot);
@@ -288,33 +276,32 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
         if (w < wave) wave_base += v;
         chunk_total += v;
       }
-      const int pos = running + wave_base + prefix[c];
+      if (keep[c])
+        lds.sort.keys[0][running + wave_base + prefix[c]] = sort_key(dist[c], i0 + c * kCompactBlock + (int)threadIdx.x);
       running += chunk_total;
-      if (keep[c]) {
-        const size_t o = (size_t)(base + pos);
-        left_of[pos] = (uint32_t)q[c];
-        st_left[o] = q[c];
-        st_right[o] = t[c];
-        st_dist[o] = d[c];
-        // the pixels as float32, as they are stored: what the triangulation of the separate launch reads back
-        // (exact: they were float32 before they were widened)
-        const float fuL = (float)uL[c], fvL = (float)vL[c], fuR = (float)uR[c], fvR = (float)vR[c];
-        st_pix_left[2 * o + 0] = fuL;
-        st_pix_left[2 * o + 1] = fvL;
-        st_pix_right[2 * o + 0] = fuR;
-        st_pix_right[2 * o + 1] = fvR;
-        lds.pix[pos] = make_float4(fuL, fvL, fuR, fvR);
-      }
     }
     __syncthreads();     // the counts have been read before the next group overwrites them
   }
-  SLAMHIP_STAMP(3);
   const int m = running;
+  SLAMHIP_STAMP(1);
+  radix_sort_lds<kCompactBlock, CAP>(lds.sort, m);
+  SLAMHIP_STAMP(2);
+  uint32_t *const left_of = lds.sort.keys[1];    // survivor -> left row, once the sort is done with the array
   if (threadIdx.x == 0) st_count[f] = m;
-  // the survivors' points, every lane busy: the pixels (float32, as stored) come from LDS
-  for (int i = threadIdx.x; i < m; i += kCompactBlock) {
-    const size_t o = (size_t)(base + i);
-    const float4 px = lds.pix[i];
+  // survivor r in sorted order: its record, and its point from the pixels kept in LDS
+  for (int r = threadIdx.x; r < m; r += kCompactBlock) {
+    const uint32_t key = lds.sort.keys[0][r];
+    const int q = (int)(key & kSortIdxMask);
+    const float4 px = lds.pix[q];
+    const size_t o = (size_t)(base + r);
+    left_of[r] = (uint32_t)q;
+    st_left[o] = q;
+    st_right[o] = lds.train[q];
+    st_dist[o] = (int)(key >> kSortKeyShift);
+    st_pix_left[2 * o + 0] = px.x;
+    st_pix_left[2 * o + 1] = px.y;
+    st_pix_right[2 * o + 0] = px.z;
+    st_pix_right[2 * o + 1] = px.w;
     double x[4];
     dlt_null_vector(cam, (double)px.x, (double)px.y, (double)px.z, (double)px.w, x);
     const float x0 = (float)x[0], x1 = (float)x[1], x2 = (float)x[2], x3 = (float)x[3];
@@ -322,6 +309,8 @@ __global__ __launch_bounds__(kCompactBlock) void stereo_tail_kernel(
     st_xyz[3 * o + 1] = x1 / x3;
     st_xyz[3 * o + 2] = x2 / x3;
   }
+  __syncthreads();      // left_of is complete
+  SLAMHIP_STAMP(3);
   SLAMHIP_STAMP(4);
   // and their descriptor rows, in survivor order (as stereo_points_kernel)
   const int lw = W == 8 ? 3 : (W == 16 ? 4 : 5);
