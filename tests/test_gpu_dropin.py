@@ -71,3 +71,63 @@ def test_reference_frame_loop_on_the_drop_in_classes(golden):
             np.testing.assert_array_equal(pix_L[mask], g[f"refine_img_{idx - 1}"])
             assert np.abs(Rt - g["relative_Rts"][idx - 1]).max() < 1e-6
         X_prev, inlier_des_L_prev = X_curr, inlier_des_L                            # :234-236
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_tracking_pipeline_with_the_references_constructor_and_build(golden, batched, tmp_path):
+    """slam_amd's TrackingPipeline takes the reference's constructor arguments and build()
+    (fill_database.py:27-38,85-255).  Image reading and feature extraction stay outside (OpenCV in
+    the reference): here an image is a frame number and the extractor returns that frame's
+    keypoints and descriptors of tests/golden/ref_build_flow.npz.  What build() hands to
+    add_frame equals what the reference's own build() handed over on the same frames; the poses
+    equal the batched front-end's bit for bit whether the frames are pushed one at a time or
+    run in one call; the two files are written as the reference writes them."""
+    import pickle
+    from oracle.tracking_db_oracle import TrackDBOracle
+    from slam_amd import CameraModel, KeyPoint
+    from slam_amd.backend.tracking import db_adapter
+    from slam_amd.backend.tracking.fill_database import TrackingPipeline
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    g = golden("ref_build_flow.npz")
+    F = int(g["n_frames"])
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+
+    class Images:                                      # ImageSequence: (left image, right image) per index
+        def __len__(self):
+            return F
+
+        def __getitem__(self, k):
+            return ("left", k), ("right", k)
+
+    class Extractor:                                   # FeatureExtractor.detect_and_compute
+        def detect_and_compute(self, img):
+            side, k = img
+            return [KeyPoint(x, y, 1) for x, y in g[f"kp_{side}_{k}"]], g[f"des_{side}_{k}"]
+
+    class DB(TrackDBOracle):
+        def serialize(self, path):
+            with open(path, "wb") as fh:
+                pickle.dump(self.summary(), fh)
+
+    with pytest.raises(ValueError):
+        TrackingPipeline(cam, Images(), 2e-3, 1.2, 4.0, False, False, "akaze", "flann", False, feature_extractor=Extractor())
+    pipe = TrackingPipeline(cam, Images(), 2e-3, 1.2, 4.0, False, False, "akaze", "bf", True,
+                            feature_extractor=Extractor(), db_factory=DB, link_factory=db_adapter.Link,
+                            batched=batched, seed=3)
+    db = pipe.build(max_frame=2600, out_path=str(tmp_path / "tracks.pkl"), rel_path=str(tmp_path / "relative_Rts"))
+    frames = [(g[f"kp_left_{k}"], g[f"kp_right_{k}"], g[f"des_left_{k}"], g[f"des_right_{k}"]) for k in range(F)]
+    want = TrackingFrontend(cam, disparity_min=1.2, pixel_thresh=4.0, seed=3).run(frames)
+    np.testing.assert_array_equal(pipe.get_relative_Rts(), want.relative_Rts())
+    with open(tmp_path / "relative_Rts", "rb") as fh:
+        np.testing.assert_array_equal(pickle.load(fh), want.relative_Rts())
+    assert (tmp_path / "tracks.pkl").exists()
+    assert np.abs(pipe.get_relative_Rts() - g["relative_Rts"]).max() < 0.05      # the reference's own samples differ
+    for k in range(F):
+        links = db.all_frame_links(k)
+        np.testing.assert_array_equal(np.asarray(links, np.float64).reshape(-1, 3), g[f"links_{k}"], err_msg=f"frame {k}")
+    ref_db = db_adapter.replay_into_db(TrackDBOracle(), want)
+    a, b = db.summary(), ref_db.summary()
+    assert a.keys() == b.keys()
+    for key in a:
+        np.testing.assert_array_equal(a[key], b[key], err_msg=key)
+    assert len(pipe.matches_per_frame) == F - 1 and all(i <= m for i, m in zip(pipe.inliers_per_frame, pipe.matches_per_frame))
