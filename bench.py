@@ -475,8 +475,8 @@ def bench_online(args):
     """The reference's own calling pattern (fill_database.py:140: one frame at a time).
     online_pair_us: one front-end call per new frame, two frames per call, features resident
     (the device-side chain).  online_push_us: OnlineFrontend.push of a new frame held in host
-    arrays (upload of that frame alone, one library call that carries the previous frame's
-    stereo stage over) followed by pose(), i.e. features in host memory to relative pose in
+    arrays (that frame alone goes up, as one packet that one library launch spreads over its
+    rows; one front-end call that carries the previous frame's stereo stage over) followed by pose(), i.e. features in host memory to relative pose in
     host memory, one frame at a time."""
     from slam_amd import CameraModel
     from slam_amd.backend.tracking.frontend import TrackingFrontend
@@ -513,8 +513,8 @@ def bench_online(args):
     return {"online_pair_us": dt * 1e6, "frames_per_sec": 1.0 / dt,
             "online_push_us": dt_push * 1e6, "push_frames_per_sec": 1.0 / dt_push,
             "push_inlier_ratio_mean": float(np.mean(inl)),
-            "note": "online_pair_us: one pair of 1500-feature frames per call, features resident: seven "
-                    "dependent launches (matcher, fused stereo tail, matcher, fused temporal tail, P3P, "
+            "note": "online_pair_us: one pair of 1500-feature frames per call, features resident: six "
+                    "dependent launches (matcher, fused stereo tail, matcher, fused temporal tail, P3P + "
                     "consensus count, replay + mask + refinement), each one or a few workgroups running a "
                     "dependent chain; online_push_us: OnlineFrontend.push(frame in host arrays).pose(), "
                     "which includes the upload of the new frame, the call and the pose's way back"}

@@ -436,6 +436,19 @@ int slamhip_frontend_pack_record(const slamhip_frontend_args *args, int frame_lo
                                  const int64_t *d_st_out_off, const int64_t *d_tm_out_off, int64_t stereo_rows,
                                  int64_t temporal_rows, uint8_t *d_record, size_t record_bytes, void *stream);
 
+/* One new frame from the host in ONE copy, for a caller that pushes frames one at a time (the
+ * shape of the reference's loop, backend/tracking/fill_database.py:140-240).  No counterpart in
+ * the reference, where the frame's arrays are host arrays already.  d_packet (4-byte aligned,
+ * device memory the caller copied the packet into): six int32 -- the window's d_off_left[0..3)
+ * and d_off_right[0..3) for a call with F <= 2 -- then the frame's left pixels (n_left x 2
+ * float32), right pixels (n_right x 2), left descriptors (n_left x desc_bytes uint8, rows
+ * packed) and right descriptors, back to back.  The call moves each piece to the device address
+ * given (the frame's first row in the caller's arrays; descriptor rows desc_stride bytes apart)
+ * and the six offsets to d_off (skipped when NULL), on `stream`, in one launch. */
+int slamhip_frontend_unpack_frame(const uint8_t *d_packet, int n_left, int n_right, int desc_bytes,
+                                  int desc_stride, float *d_kp_left, float *d_kp_right, uint8_t *d_des_left,
+                                  uint8_t *d_des_right, int32_t *d_off, void *stream);
+
 /* ------------------------------------------------------------------------- */
 /* Pair verification: LoopClosure.consensus_pnp_match                        */
 /* (backend/optimizers/loop_closure.py:167-235) for a LIST of                */

@@ -140,6 +140,7 @@ SIGNATURES["slamhip_frontend_batch"] = (_i, [C.POINTER(FrontendArgs), _vp])
 SIGNATURES["slamhip_frontend_record_bytes"] = (_sz, [_i, _i, C.c_longlong, C.c_longlong, _i])
 SIGNATURES["slamhip_frontend_pack_record"] = (_i, [C.POINTER(FrontendArgs), _i, _i, _i, _i, C.c_int64, C.c_int64,
                                                    _vp, _vp, C.c_int64, C.c_int64, _vp, _sz, _vp])
+SIGNATURES["slamhip_frontend_unpack_frame"] = (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
 
 for _name, (_res, _args) in SIGNATURES.items():
     _fn = getattr(lib, _name)  # AttributeError here = header and library disagree

@@ -154,7 +154,7 @@ class OnlineFrontend:
         self._buf = buf
         if old is None:
             self._pin_record = torch.zeros(16, dtype=torch.float64, pin_memory=True)
-            self._pin_in = None
+            self._pin_in = self._pin_np = self._packet = None
             self._off_event = self._ev = None
         return old
 
@@ -206,34 +206,37 @@ class OnlineFrontend:
         F = 1 if first else 2
         pl, pr = (0, 0) if first else (self._nl, self._nr)      # rows of the previous frame in the window
         off = np.array([0, pl, pl + nl, 0, pr, pr + nr] if not first else [0, nl, nl, 0, nr, nr], dtype=np.int32)
-        # the new frame and the window's offsets go through one page-locked buffer (asynchronous
-        # copies; the buffer is free again once the copies of the push before have been made)
+        # the new frame and the window's offsets go to the device as one packet: staged in a
+        # page-locked buffer (free again once the copy of the push before has been made), one
+        # asynchronous copy, one library launch that moves the pieces to their rows
         need = 24 + 8 * (nl + nr) + D * (nl + nr)
         if self._off_event is not None:
             self._off_event.synchronize()
         if self._pin_in is None or self._pin_in.numel() < need:
             self._pin_in = torch.empty(int(need * 1.5), dtype=torch.uint8, pin_memory=True)
-        stage, at = self._pin_in, 0
-        stage[:24].view(torch.int32).numpy()[:] = off
-        b["off"].copy_(stage[:24].view(torch.int32), non_blocking=True)
-        at = 24
-        for name, arr, row, n in (("kp_left", kp_left, new_l, nl), ("kp_right", kp_right, new_r, nr),
-                                  ("des_left", des_left, new_l, nl), ("des_right", des_right, new_r, nr)):
-            if n:
-                nb = arr.nbytes
-                piece = stage[at:at + nb].view(b[name].dtype).view(n, -1)
-                piece.numpy()[:] = arr
-                b[name][row:row + n].copy_(piece, non_blocking=True)
-                at += nb
+            self._pin_np = self._pin_in.numpy()
+        if self._packet is None or self._packet.numel() < need or self._packet.device != dev:
+            self._packet = torch.empty(int(need * 1.5), dtype=torch.uint8, device=dev)
+        stage, at = self._pin_np, 24
+        stage[:24].view(np.int32)[:] = off
+        for arr in (kp_left, kp_right, des_left, des_right):
+            nb = arr.nbytes
+            stage[at:at + nb] = arr.reshape(-1).view(np.uint8)
+            at += nb
+        self._packet[:need].copy_(self._pin_in[:need], non_blocking=True)
         if self._ev is None:
             self._ev = torch.cuda.Event()
         self._off_event = self._ev
         self._off_event.record(stream)
+        where = b["where"]
+        addr = lambda name, row: where[name][0] + row * where[name][1]      # device address of a row
+        check(lib.slamhip_frontend_unpack_frame(self._packet.data_ptr(), nl, nr, D, D, addr("kp_left", new_l),
+                                                addr("kp_right", new_r), addr("des_left", new_l),
+                                                addr("des_right", new_r), b["off"].data_ptr(), stream.cuda_stream),
+              "slamhip_frontend_unpack_frame")
         wl, wr = (new_l, new_r) if first else (self._ol, self._or)   # first row of the window
         NL, NR = pl + nl, pr + nr
         slot = self._slot                        # per-frame entry of the window's first frame
-        where = b["where"]
-        addr = lambda name, row: where[name][0] + row * where[name][1]      # device address of a row
         a = self._arguments()
         a.n_frames, a.n_left_total, a.n_right_total = F, NL, NR
         a.max_left, a.max_right = max(pl, nl), max(pr, nr)

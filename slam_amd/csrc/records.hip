@@ -126,6 +126,43 @@ __global__ __launch_bounds__(256) void pack_record_kernel(
   }
 }
 
+/* One new frame's packet -> the rows of the caller's arrays it belongs at.  blockIdx.y names the
+ * piece: 0 left pixels, 1 right pixels (both as 32-bit words), 2 left descriptors, 3 right
+ * descriptors (bytes: a row of `stride` bytes need not start on a word), 4 the six offsets. */
+__global__ __launch_bounds__(256) void unpack_frame_kernel(const uint8_t *__restrict__ packet, const int n_left,
+                                                           const int n_right, const int D, const int stride,
+                                                           float *__restrict__ kp_left, float *__restrict__ kp_right,
+                                                           uint8_t *__restrict__ des_left,
+                                                           uint8_t *__restrict__ des_right, int32_t *__restrict__ off) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+  const size_t at_kp_left = 24, at_kp_right = at_kp_left + 8 * (size_t)n_left,
+               at_des_left = at_kp_right + 8 * (size_t)n_right, at_des_right = at_des_left + (size_t)D * n_left;
+  switch (blockIdx.y) {
+    case 0:
+    case 1: {
+      const uint32_t *src = (const uint32_t *)(packet + (blockIdx.y == 0 ? at_kp_left : at_kp_right));
+      uint32_t *dst = (uint32_t *)(blockIdx.y == 0 ? kp_left : kp_right);
+      const int words = 2 * (blockIdx.y == 0 ? n_left : n_right);
+      for (int i = tid; i < words; i += step) dst[i] = src[i];
+      break;
+    }
+    case 2:
+    case 3: {
+      const uint8_t *src = packet + (blockIdx.y == 2 ? at_des_left : at_des_right);
+      uint8_t *dst = blockIdx.y == 2 ? des_left : des_right;
+      const long long bytes = (long long)D * (blockIdx.y == 2 ? n_left : n_right);
+      if (stride == D) {
+        for (long long i = tid; i < bytes; i += step) dst[i] = src[i];
+      } else {
+        for (long long i = tid; i < bytes; i += step) dst[(i / D) * stride + i % D] = src[i];
+      }
+      break;
+    }
+    default:
+      if (off && tid < 6) off[tid] = ((const int32_t *)packet)[tid];
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -163,6 +200,22 @@ int slamhip_frontend_pack_record(const slamhip_frontend_args *a, int frame_lo, i
                      a->d_st_dist, a->d_st_xyz, a->d_st_pix_left, a->d_st_pix_right, a->d_st_desc, a->d_tm_query,
                      a->d_tm_train, a->d_tm_dist, a->d_tm_mask, a->d_pose_refined, a->d_pose_ransac,
                      a->d_ransac_info, d_record);
+  SLAMHIP_CHECK_LAUNCH();
+  return SLAMHIP_OK;
+}
+
+int slamhip_frontend_unpack_frame(const uint8_t *d_packet, int n_left, int n_right, int desc_bytes,
+                                  int desc_stride, float *d_kp_left, float *d_kp_right, uint8_t *d_des_left,
+                                  uint8_t *d_des_right, int32_t *d_off, void *stream) {
+  SLAMHIP_BEGIN();
+  if (!d_packet || n_left < 0 || n_right < 0 || desc_bytes < 1 || desc_stride < desc_bytes ||
+      ((uintptr_t)d_packet & 3) || (n_left > 0 && (!d_kp_left || !d_des_left)) ||
+      (n_right > 0 && (!d_kp_right || !d_des_right)))
+    return SLAMHIP_EINVAL;
+  const long long most = (long long)desc_bytes * (n_left > n_right ? n_left : n_right);
+  const int blocks = most > 256 * 64 ? 64 : (most > 256 ? (int)slamhip_ceil_div((int)most, 256) : 1);
+  hipLaunchKernelGGL(unpack_frame_kernel, dim3(blocks, 5), dim3(256), 0, (hipStream_t)stream, d_packet, n_left,
+                     n_right, desc_bytes, desc_stride, d_kp_left, d_kp_right, d_des_left, d_des_right, d_off);
   SLAMHIP_CHECK_LAUNCH();
   return SLAMHIP_OK;
 }

@@ -106,6 +106,7 @@ def test_argument_structs_match_the_header_and_are_size_checked(tmp_path):
     assert _lib.lib.slamhip_frontend_workspace_bytes(C.byref(a)) == 0
     assert _lib.lib.slamhip_frontend_batch(C.byref(a), None) == _lib.EINVAL
     assert _lib.lib.slamhip_frontend_pack_record(C.byref(a), 0, 1, 0, 0, 0, 0, None, None, 0, 0, None, 0, None) == _lib.EINVAL
+    assert _lib.lib.slamhip_frontend_unpack_frame(None, 1, 1, 61, 61, None, None, None, None, None, None) == _lib.EINVAL
     v = _lib.VerifyArgs()
     v.desc_bytes = v.desc_stride = 61
     v.n_iter_max = 10

@@ -796,3 +796,47 @@ def test_pushing_frames_one_at_a_time_equals_the_batched_call(cross):
     online.reset()
     assert online.push(*frames[1]) is None
     np.testing.assert_array_equal(online.push(*frames[2]).pair(0)["query_idx"], want.pair(1)["query_idx"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_left,n_right,nbytes,stride", [(1500, 1400, 61, 61), (7, 0, 32, 40), (0, 5, 61, 64),
+                                                           (0, 0, 61, 61), (4097, 3, 1, 1)])
+def test_one_packet_per_frame_reaches_the_rows_it_names(n_left, n_right, nbytes, stride):
+    """slamhip_frontend_unpack_frame: the packet's five pieces land at the addresses given and
+    nothing next to them changes."""
+    from slam_amd import _lib
+    import ctypes as C
+    rng = np.random.default_rng(n_left + 3 * n_right)
+    off = rng.integers(0, 1 << 20, 6).astype(np.int32)
+    kp_l = rng.random((n_left, 2), dtype=np.float32)
+    kp_r = rng.random((n_right, 2), dtype=np.float32)
+    de_l = rng.integers(0, 256, (n_left, nbytes), dtype=np.uint8)
+    de_r = rng.integers(0, 256, (n_right, nbytes), dtype=np.uint8)
+    packet = np.concatenate([a.reshape(-1).view(np.uint8) for a in (off, kp_l, kp_r, de_l, de_r)])
+    d_packet = torch.from_numpy(packet).cuda()
+    row_l, row_r = 3, 5                                  # where the frame starts in the caller's arrays
+    fill = 0xA5
+    d_kp_l = torch.full((row_l + n_left + 2, 2), float("nan"), device="cuda")
+    d_kp_r = torch.full((row_r + n_right + 2, 2), float("nan"), device="cuda")
+    d_de_l = torch.full((row_l + n_left + 2, stride), fill, dtype=torch.uint8, device="cuda")
+    d_de_r = torch.full((row_r + n_right + 2, stride), fill, dtype=torch.uint8, device="cuda")
+    d_off = torch.full((8,), -1, dtype=torch.int32, device="cuda")
+    for with_off in (True, False):
+        rc = _lib.lib.slamhip_frontend_unpack_frame(
+            d_packet.data_ptr(), n_left, n_right, nbytes, stride, d_kp_l[row_l:].data_ptr(), d_kp_r[row_r:].data_ptr(),
+            d_de_l[row_l:].data_ptr(), d_de_r[row_r:].data_ptr(), d_off.data_ptr() if with_off else None,
+            torch.cuda.current_stream().cuda_stream)
+        assert rc == _lib.OK
+        torch.cuda.synchronize()
+        for got, want, row, n in ((d_kp_l, kp_l, row_l, n_left), (d_kp_r, kp_r, row_r, n_right)):
+            g = got.cpu().numpy()
+            assert np.array_equal(g[row:row + n], want)
+            assert np.isnan(g[:row]).all() and np.isnan(g[row + n:]).all()
+        for got, want, row, n in ((d_de_l, de_l, row_l, n_left), (d_de_r, de_r, row_r, n_right)):
+            g = got.cpu().numpy()
+            assert np.array_equal(g[row:row + n, :nbytes], want)
+            assert (g[:row] == fill).all() and (g[row + n:] == fill).all() and (g[:, nbytes:] == fill).all()
+        assert np.array_equal(d_off.cpu().numpy(), np.concatenate([off, [-1, -1]]))
+    assert _lib.lib.slamhip_frontend_unpack_frame(d_packet.data_ptr(), 1, 0, nbytes, nbytes - 1, d_kp_l.data_ptr(),
+                                                  d_kp_r.data_ptr(), d_de_l.data_ptr(), d_de_r.data_ptr(), None,
+                                                  None) == _lib.EINVAL
