@@ -474,7 +474,7 @@ def bench_sequence(args, rank, world, dist, red_dev="cuda"):
 def bench_online(args):
     """The reference's own calling pattern (fill_database.py:140: one frame at a time).
     online_pair_us: one front-end call per new frame, two frames per call, features resident
-    (the device-side chain).  online_push_us: OnlineFrontend.push of a new frame held in host
+    (the device-side chain; online_pair_run_us: the same through TrackingFrontend.run).  online_push_us: OnlineFrontend.push of a new frame held in host
     arrays (that frame alone goes up, as one packet that one library launch spreads over its
     rows; one front-end call that carries the previous frame's stereo stage over) followed by pose(), i.e. features in host memory to relative pose in
     host memory, one frame at a time."""
@@ -496,6 +496,21 @@ def bench_online(args):
     for _ in range(reps):
         fe.run(inp)
     torch.cuda.synchronize()
+    dt_run = (time.perf_counter() - t0) / reps
+    # the same call with its argument block kept (what OnlineFrontend does from push to push):
+    # no allocations, no argument conversion on the host, so the figure is the device's chain
+    # and not this box's Python speed
+    import ctypes as C
+    from slam_amd import _lib
+    res = fe.run(inp)
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(20):
+        _lib.check(_lib.lib.slamhip_frontend_batch(C.byref(res.args), stream), "slamhip_frontend_batch")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        _lib.lib.slamhip_frontend_batch(C.byref(res.args), stream)
+    torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     online = OnlineFrontend(cam)
     for f in frames[:4]:
@@ -510,10 +525,12 @@ def bench_online(args):
         Rt, info = online.push(*f).pose()
         inl.append(info[6] / max(info[5], 1))
     dt_push = (time.perf_counter() - t0) / (n_seq - 1)
-    return {"online_pair_us": dt * 1e6, "frames_per_sec": 1.0 / dt,
+    return {"online_pair_us": dt * 1e6, "frames_per_sec": 1.0 / dt, "online_pair_run_us": dt_run * 1e6,
             "online_push_us": dt_push * 1e6, "push_frames_per_sec": 1.0 / dt_push,
             "push_inlier_ratio_mean": float(np.mean(inl)),
-            "note": "online_pair_us: one pair of 1500-feature frames per call, features resident: six "
+            "note": "online_pair_us: one pair of 1500-feature frames per call (slamhip_frontend_batch on a kept "
+                    "argument block; online_pair_run_us: through TrackingFrontend.run, which allocates the "
+                    "outputs and builds the block per call), features resident: six "
                     "dependent launches (matcher, fused stereo tail, matcher, fused temporal tail, P3P + "
                     "consensus count, replay + mask + refinement), each one or a few workgroups running a "
                     "dependent chain; online_push_us: OnlineFrontend.push(frame in host arrays).pose(), "
