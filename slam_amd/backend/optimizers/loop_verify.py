@@ -104,26 +104,71 @@ class PairVerifier:
     def set_keyframes(self, keyframes: Sequence[Tuple[np.ndarray, np.ndarray]]):
         """keyframes[i] = (links (n,3) float64 rows [x_left, x_right, y], des_left (n,D) uint8):
         what LoopClosure.frame_data reads back from the TrackingDB."""
-        n = [len(k[0]) for k in keyframes]
+        self._kf = None
+        self.add_keyframes(keyframes)
+        return self
+
+    def add_keyframes(self, keyframes: Sequence[Tuple[np.ndarray, np.ndarray]]) -> range:
+        """Appends keyframes to the ones already set (a caller that meets its keyframes one at a
+        time, as the loop of run_loop_closure does, loop_closure.py:321-346); returns the indices
+        they got.  The device arrays grow by doubling, so adding keyframes one by one uploads
+        every row once (and copies it device to device a few times)."""
         for links, des in keyframes:
             if len(links) != len(des):
                 raise ValueError("links and descriptors differ in length")
-        off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+        if not len(keyframes):
+            n_have = 0 if self._kf is None else len(self._kf["n"])
+            if self._kf is None:
+                self._kf = self._empty_store(61)
+            return range(n_have, n_have)
         links = np.concatenate([np.asarray(k[0], dtype=np.float64).reshape(-1, 3) for k in keyframes])
-        des = np.concatenate([np.asarray(k[1], dtype=np.uint8) for k in keyframes])
+        des = [np.asarray(k[1], dtype=np.uint8) for k in keyframes]
+        D = next((d.shape[1] for d in des if d.ndim == 2 and d.shape[1] > 0), 61)
+        des = np.concatenate([d.reshape(-1, D) for d in des])
+        if self._kf is None:
+            self._kf = self._empty_store(D)
+        kf = self._kf
+        if kf["D"] != D:
+            if kf["off"][-1] != 0:
+                raise ValueError("descriptor width differs from the keyframes already set")
+            self._kf = kf = self._empty_store(D)
         # LoopClosure.frame_data rebuilds the keypoints as cv2.KeyPoint(x, y, 1)
         # (loop_closure.py:152-164), which stores float32: the fp64 triangulation sees the
         # link coordinates rounded to float32, and Link.y = (yL + yR) / 2 is in general
         # not a float32 value.
         kp_l32 = np.ascontiguousarray(links[:, [0, 2]]).astype(np.float32)
         kp_r32 = np.ascontiguousarray(links[:, [1, 2]]).astype(np.float32)
-        kp_l, kp_r = kp_l32.astype(np.float64), kp_r32.astype(np.float64)
-        self._kf_host = (kp_l32, off)      # left pixels as cv2.KeyPoint keeps them
-        self._kf = {"n": np.asarray(n, dtype=np.int64), "off": off,
-                    "kp_l": kernels.to_device(kp_l, torch.float64),
-                    "kp_r": kernels.to_device(kp_r, torch.float64),
-                    "des": kernels.to_device(des, torch.uint8)}
-        return self
+        first, at = len(kf["n"]), int(kf["off"][-1])
+        n_new = [len(k[0]) for k in keyframes]
+        rows = at + len(links)
+        if rows > kf["cap"]:
+            cap = max(2 * kf["cap"], rows, 1024)
+            dev = kernels._require_gpu()
+            for name, width, dt in (("kp_l", 2, torch.float64), ("kp_r", 2, torch.float64), ("des", D, torch.uint8)):
+                grown = torch.empty((cap, width), dtype=dt, device=dev)
+                if at:
+                    grown[:at].copy_(kf[name][:at])
+                kf[name] = grown
+            kf["cap"] = cap
+        if len(links):
+            kf["kp_l"][at:rows].copy_(kernels.to_device(kp_l32.astype(np.float64), torch.float64))
+            kf["kp_r"][at:rows].copy_(kernels.to_device(kp_r32.astype(np.float64), torch.float64))
+            kf["des"][at:rows].copy_(kernels.to_device(des, torch.uint8))
+        kf["n"] = np.concatenate([kf["n"], np.asarray(n_new, dtype=np.int64)])
+        kf["off"] = np.concatenate([[0], np.cumsum(kf["n"])]).astype(np.int64)
+        lo = 0
+        for n in n_new:                  # left pixels as cv2.KeyPoint keeps them, per keyframe
+            self._kf_host.append(kp_l32[lo:lo + n])
+            lo += n
+        return range(first, first + len(keyframes))
+
+    def _empty_store(self, D: int) -> dict:
+        dev = kernels._require_gpu()
+        self._kf_host = []
+        return {"n": np.zeros(0, np.int64), "off": np.zeros(1, np.int64), "cap": 0, "D": int(D),
+                "kp_l": torch.empty((0, 2), dtype=torch.float64, device=dev),
+                "kp_r": torch.empty((0, 2), dtype=torch.float64, device=dev),
+                "des": torch.empty((0, int(D)), dtype=torch.uint8, device=dev)}
 
     def verify(self, pairs, pair_ids=None, samples=None) -> dict:
         """pairs: (P,2) int array of (candidate, current) keyframe indices.
@@ -226,31 +271,46 @@ class PairVerifier:
         }
         return VerifyResult(host, out, O, N)
 
-    def consensus_pnp_match(self, kf_curr: int, kf_cand: int, pose_factory=None):
+    def consensus_pnp_match(self, kf_curr: int, kf_cand: int, pose_factory=None, pair_id=None):
         """One pair, shaped like the reference's method (loop_closure.py:167-235):
         (True, Delta_inv, mask, (kf_curr, kf_cand), px) or (False, None, None, (None, None), {}).
         kf_curr / kf_cand index the list given to set_keyframes.  Delta_inv is
         `pose_factory(R, t).inverse()` when a factory is given (the reference builds
         gtsam.Pose3(gtsam.Rot3(R), gtsam.Point3(t)), loop_closure.py:226-228), else the
         inverse pose as a 4 x 4 array.  px holds the left pixels of inlier and outlier
-        matches in both keyframes (float32), as loop_closure.py:230-233.  A caller with many
-        candidates per keyframe should hand all pairs to verify() at once."""
-        res = self.verify(np.array([[kf_cand, kf_curr]], dtype=np.int64))
-        if not bool(res["ok"][0]):
-            return (False, None, None, (None, None), {})
-        m = res.pair_matches(0)
-        mask = m["mask"]
-        kp_l, off = self._kf_host
-        pts_curr = kp_l[off[kf_curr] + m["train_idx"].astype(np.int64)]
-        pts_cand = kp_l[off[kf_cand] + m["query_idx"].astype(np.int64)]
-        Rt = res["Rt"][0]
-        R, t = Rt[:, :3], Rt[:, 3]
-        if pose_factory is not None:
-            delta_inv = pose_factory(R, t).inverse()
-        else:
-            delta_inv = np.eye(4)
-            delta_inv[:3, :3] = R.T
-            delta_inv[:3, 3] = -R.T @ t
-        px = dict(inl_curr=pts_curr[mask], out_curr=pts_curr[~mask],
-                  inl_cand=pts_cand[mask], out_cand=pts_cand[~mask])
-        return (True, delta_inv, mask, (kf_curr, kf_cand), px)
+        matches in both keyframes (float32), as loop_closure.py:230-233.  `pair_id`: the
+        sampler key of the pair (default 0).  A caller with many candidates per keyframe
+        should hand them to consensus_pnp_matches, or all pairs to verify(), at once."""
+        return self.consensus_pnp_matches(kf_curr, [kf_cand], pose_factory,
+                                          None if pair_id is None else [pair_id])[0]
+
+    def consensus_pnp_matches(self, kf_curr: int, kf_cands, pose_factory=None, pair_ids=None) -> list:
+        """The candidates of one keyframe (the `for i_kf in cand_kf_idxs` loop of
+        loop_closure.py:341-346, whose iterations do not depend on one another) in one call: a
+        list with consensus_pnp_match's tuple per candidate."""
+        kf_cands = [int(c) for c in kf_cands]
+        if not kf_cands:
+            return []
+        pairs = np.array([[c, kf_curr] for c in kf_cands], dtype=np.int64)
+        res = self.verify(pairs, pair_ids=pair_ids)
+        out = []
+        for p, kf_cand in enumerate(kf_cands):
+            if not bool(res["ok"][p]):
+                out.append((False, None, None, (None, None), {}))
+                continue
+            m = res.pair_matches(p)
+            mask = m["mask"]
+            pts_curr = self._kf_host[kf_curr][m["train_idx"].astype(np.int64)]
+            pts_cand = self._kf_host[kf_cand][m["query_idx"].astype(np.int64)]
+            Rt = res["Rt"][p]
+            R, t = Rt[:, :3], Rt[:, 3]
+            if pose_factory is not None:
+                delta_inv = pose_factory(R, t).inverse()
+            else:
+                delta_inv = np.eye(4)
+                delta_inv[:3, :3] = R.T
+                delta_inv[:3, 3] = -R.T @ t
+            px = dict(inl_curr=pts_curr[mask], out_curr=pts_curr[~mask],
+                      inl_cand=pts_cand[mask], out_cand=pts_cand[~mask])
+            out.append((True, delta_inv, mask, (kf_curr, kf_cand), px))
+        return out

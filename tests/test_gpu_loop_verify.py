@@ -564,3 +564,110 @@ def test_pairs_with_more_matches_than_a_sample_index_field_holds():
     assert got[1]["n_matches"][0] == n and 1 <= got[1]["iterations"][0] <= 300
     for k in got[1]:
         np.testing.assert_array_equal(got[1][k], got[2][k], err_msg=k)
+
+
+class _LinkRow:
+    def __init__(self, row):
+        self.x_left, self.x_right, self.y = (float(v) for v in row)
+
+
+class _KeyframeDB:
+    """What consensus_pnp_match reads of a TrackingDB (loop_closure.py:157-158)."""
+
+    def __init__(self, g, ids):
+        self._links = {k: [_LinkRow(r) for r in g[f"links_{k}"]] for k in ids}
+        self._des = {k: g[f"des_{k}"] for k in ids}
+        self.reads = []
+
+    def features(self, kf):
+        self.reads.append(kf)
+        return self._des[kf]
+
+    def all_frame_links(self, kf):
+        return self._links[kf]
+
+
+@pytest.mark.gpu
+def test_consensus_check_with_the_references_signature_reads_the_tracking_db(golden):
+    """ConsensusCheck.consensus_pnp_match(kf_curr, kf_cand, db) (the signature of
+    loop_closure.py:167) on the keyframes of the reference's own run: keyframes are read from
+    the DB and uploaded the first time they are met, one by one; the results are those of
+    PairVerifier over the whole keyframe list with the same sampler keys, bit for bit, the
+    decisions are the reference's, and the candidates of a keyframe checked in one call give
+    what they give one by one."""
+    from slam_amd import CameraModel
+    from slam_amd.backend.optimizers.loop_closure import ConsensusCheck, GpuConsensusCheck
+    from slam_amd.backend.optimizers.loop_verify import PairVerifier
+    g = golden("ref_consensus_flow.npz")
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+    ids = sorted(int(k.split("_")[1]) for k in g.files if k.startswith("links_"))
+    keyframes = [(g[f"links_{k}"], g[f"des_{k}"]) for k in ids]
+    seen = set()
+    for i, (curr, cand, gate, cc) in enumerate(g["cases"]):
+        curr, cand = int(curr), int(cand)
+        db = _KeyframeDB(g, ids)
+        chk = ConsensusCheck(cam, frame_cross_check=bool(cc), min_inliers_loop=int(gate), seed=i)
+        out = chk.consensus_pnp_match(curr, cand, db)
+        assert len(out) == 5 and out[0] == bool(g[f"ok_{i}"])
+        seen.add(out[0])
+        again = chk.consensus_pnp_match(curr, cand, db)
+        assert sorted(db.reads) == sorted({curr, cand})                   # each keyframe read once
+        whole = PairVerifier(cam, pixel_thresh=1.5, min_inliers_loop=int(gate), seed=i,
+                             frame_cross_check=bool(cc)).set_keyframes(keyframes)
+        res = whole.verify(np.array([[ids.index(cand), ids.index(curr)]]), pair_ids=[(curr << 24) ^ cand])
+        assert bool(res["ok"][0]) == out[0]
+        if not out[0]:
+            assert out[1:] == (None, None, (None, None), {}) and again == out
+            continue
+        ok, delta_inv, mask, pair, px = out
+        assert pair == (curr, cand)                                        # frame ids, as :235
+        np.testing.assert_array_equal(mask, res.pair_matches(0)["mask"])
+        np.testing.assert_array_equal(mask, again[2])
+        T = np.eye(4)
+        T[:3] = res["Rt"][0]
+        np.testing.assert_allclose(delta_inv @ T, np.eye(4), atol=1e-12)
+        np.testing.assert_array_equal(delta_inv, again[1])
+        assert np.abs(delta_inv - g[f"delta_inv_{i}"])[:3, :3].max() < 5e-3
+        assert len(px["inl_curr"]) == len(px["inl_cand"]) == mask.sum()
+        assert {tuple(r) for r in g[f"inl_curr_{i}"]} <= {tuple(r) for r in np.vstack([px["inl_curr"], px["out_curr"]])}
+    assert seen == {True, False}
+
+    # all candidates of one keyframe in one call = one by one; keyframes met in any order
+    db = _KeyframeDB(g, ids)
+    chk = ConsensusCheck(cam, min_inliers_loop=60)
+    curr, cands = ids[-1], ids[:-1]
+    together = chk.consensus_pnp_matches(curr, cands, db)
+    alone = ConsensusCheck(cam, min_inliers_loop=60)
+    for c, t in zip(reversed(cands), reversed(together)):
+        o = alone.consensus_pnp_match(curr, c, db)
+        assert o[0] == t[0] and o[3] == t[3]
+        if o[0]:
+            np.testing.assert_array_equal(o[2], t[2])
+            np.testing.assert_array_equal(o[1], t[1])
+    assert chk.consensus_pnp_matches(curr, [], db) == []
+
+    # frame_data / compute_triangulation, the two helpers of the method (:152-164, :237-249)
+    kpL, kpR, desL = chk.frame_data(db, ids[0])
+    links = g[f"links_{ids[0]}"]
+    assert kpL.dtype == np.float32 and kpL.shape == (len(links), 2) and desL is db._des[ids[0]]
+    np.testing.assert_array_equal(kpL, links[:, [0, 2]].astype(np.float32))
+    np.testing.assert_array_equal(kpR, links[:, [1, 2]].astype(np.float32))
+    xyz = chk.compute_triangulation(cam.P_left, cam.P_right, kpL, kpR)
+    assert xyz.dtype == np.float64 and xyz.shape == (len(links), 3)
+    ref = so.triangulate_cv(cam.P_left, cam.P_right, kpL.astype(np.float64), kpR.astype(np.float64), out_fp64=True)
+    np.testing.assert_allclose(xyz, ref, rtol=1e-9, atol=1e-9)
+
+    # as a mix-in: the attributes LoopClosure.__init__ sets are what it reads (:32-40)
+    class RefShaped:
+        def __init__(self, cam, frame_cross_check, min_inliers_loop=60):
+            from slam_amd.frontend.geometry.pnp import PnP
+            self.pnp = PnP(cam, 1.5)
+            self.frame_cross_check, self.min_inliers_loop = frame_cross_check, min_inliers_loop
+
+    class Mixed(GpuConsensusCheck, RefShaped):
+        pass
+    mixed = Mixed(cam, False, 60).consensus_pnp_matches(curr, cands, db)
+    for a, b in zip(mixed, together):
+        assert a[0] == b[0] and a[3] == b[3]
+        if a[0]:
+            np.testing.assert_array_equal(a[2], b[2])
