@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
 #endif
 #if (SLAMHIP_ABLATE & 64)  // timing experiment: start and end of every block in 100 MHz ticks, behind dist2
   const unsigned span0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+  unsigned span_prologue = span0, span_loop = span0;
 #endif
   const uint32_t m8 = 0x88888888u, m2 = 0x22222222u;
 
@@ -389,6 +390,9 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     store_ctab(0, r_begin);
     load_stage(r_begin + R);
     __syncthreads();
+#if (SLAMHIP_ABLATE & 64)
+    span_prologue = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     if (PIPE) {
 #pragma unroll
       for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const v4i *>(lbase + aoff[s]);
@@ -419,6 +423,9 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
         }
       }
     }
+#if (SLAMHIP_ABLATE & 64)
+    span_loop = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
 #pragma unroll
     for (int g = 0; g < G; ++g) fold16<BEST>(accB[g], b1[g], b2[g]);
   }
@@ -511,7 +518,7 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
   }
 #if (SLAMHIP_ABLATE & 64)
   if (tid == 0 && blockIdx.z == 0) {
-    int *o = dist2 + 2 * (size_t)nq_total + 4 * (blockIdx.y * gridDim.x + blockIdx.x);
+    int *o = dist2 + 2 * (size_t)nq_total + 8 * (blockIdx.y * gridDim.x + blockIdx.x);
     unsigned xcc, hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -519,6 +526,8 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     o[1] = (int)(unsigned)__builtin_amdgcn_s_memrealtime();
     o[2] = (int)xcc;
     o[3] = (int)hw;
+    o[4] = (int)span_prologue;
+    o[5] = (int)span_loop;
   }
 #endif
 #if (SLAMHIP_ABLATE & 32)  // slots 38 / 39: the wave's lifetime in shader cycles and in 100 MHz ticks

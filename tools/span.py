@@ -31,13 +31,17 @@ torch.cuda.synchronize()
 ms = C.c_double(0.0)
 k = _lib.lib.slamhip_profile_end(C.byref(ms))
 tail = d2.cpu().numpy()[2 * n:].astype(np.int64) & 0xFFFFFFFF
-nb = (n // 256) * splits if variant == 10 else (n // 128) * splits
-rec = tail[:4 * nb].reshape(nb, 4)
+qpb = 512 if variant == 18 else (256 if variant == 10 else 128)     # queries per block
+nb = (n // qpb) * splits
+rec = tail[:8 * nb].reshape(nb, 8)
 se = rec[:, :2]
 st, en = se[:, 0] - se[:, 0].min(), se[:, 1] - se[:, 0].min()
 print(f"event-timed kernel {ms.value / k * 1e3:.2f} us; blocks {nb}: start spread {st.max() / 100:.2f} us, "
       f"first start -> last end {en.max() / 100:.2f} us, block lifetime median {np.median(en - st) / 100:.2f} "
       f"min {(en - st).min() / 100:.2f} max {(en - st).max() / 100:.2f} us, first end {en.min() / 100:.2f} us")
+pro, loop = (rec[:, 4] - rec[:, 0]) / 100, (rec[:, 5] - rec[:, 4]) / 100
+print(f"wave 0 of a block: prologue (to the first barrier) median {np.median(pro):.2f} us, stage loop {np.median(loop):.2f} us, "
+      f"epilogue {np.median((rec[:, 1] - rec[:, 5]) / 100):.2f} us")
 life = (en - st) / 100
 xcc = rec[:, 2] & 0xF
 hw = rec[:, 3]
@@ -52,6 +56,6 @@ for c in np.unique(nb_on_cu):
 for x in range(8):
     m = xcc == x
     print(f"  xcc {x}: n={m.sum()} lifetime median {np.median(life[m]):.2f} max {life[m].max():.2f}, end max {en[m].max() / 100:.2f} us")
-qb = n // (256 if variant == 10 else 128)
+qb = n // qpb
 bid = np.arange(nb)
 print("  by split (median lifetime):", np.round([np.median(life[bid // qb == sp]) for sp in range(splits)], 2))
