@@ -308,6 +308,9 @@ def bench_frontend(args, rank, world, dist, red_dev="cuda", deferred=None):
     for chunk in (64, 128, 256):
         if chunk < F - 1:
             variants[f"chunks_of_{chunk}_pairs"] = timed(lambda: fe.run_chunked(packed, chunk_pairs=chunk))
+    for chunk in (128, 167):
+        if chunk < F - 1:       # every upload queued back to back, no frame's stereo stage twice
+            variants[f"streamed_{chunk}_pairs"] = timed(lambda: fe.run_streamed(packed, chunk_pairs=chunk))
     best = min(variants, key=variants.get)
     e2e = variants[best]
     out_bytes = sum(v.nbytes for v in fe.run(fe.upload(packed)).to_host().values())

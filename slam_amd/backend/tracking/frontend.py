@@ -315,6 +315,173 @@ class TrackingFrontend:
             out.to_host()
         return out
 
+    def run_streamed(self, packed: PackedFrames, chunk_pairs: int = 64, samples: Optional[np.ndarray] = None
+                     ) -> FrontendResult:
+        """A sequence held in page-locked host memory, features up and results down while the
+        passes run, as ONE result over the whole sequence (device arrays in `t`, the host copies
+        already made).  All host-to-device copies are queued back to back on a second stream at
+        the start, so that direction of the host link never waits for the host: the frames land
+        in whole-sequence device arrays, `chunk_pairs` pairs' worth at a time with an event behind
+        each piece; the passes follow the events on the current stream, each over the window
+        [its first frame, its last frame] of those arrays, the stereo stage of a window's first
+        frame being the one the window before has left in place (first_stereo_frame = 1: no
+        frame is processed twice); a third stream copies every finished window's rows to the
+        host.  Same results as run() over the whole sequence."""
+        F = len(packed)
+        if F < 2:
+            return self.run(self.upload(packed), samples=samples)
+        chunk_pairs = max(1, int(chunk_pairs))
+        off_l, off_r = np.asarray(packed.off_left, np.int64), np.asarray(packed.off_right, np.int64)
+        NL, NR = int(off_l[-1]), int(off_r[-1])
+        kl_h, kr_h, dl_h, dr_h = packed.tensors()
+        if dl_h.dim() != 2 or kl_h.dtype != torch.float32 or dl_h.dtype != torch.uint8:
+            raise ValueError("keypoints must be float32 (n, 2) and descriptors uint8 (n, D)")
+        D = int(dl_h.shape[1])
+        W = 8 if D <= 32 else (16 if D <= 64 else 32)
+        main = torch.cuda.current_stream()
+        dev = main.device
+        s_in, s_out = self._side_streams()
+        s_in.wait_stream(main)
+        s_out.wait_stream(main)
+        starts = list(range(0, F - 1, chunk_pairs))
+        windows = [(a, min(a + chunk_pairs, F - 1)) for a in starts]          # frames a .. b inclusive
+        # offsets: the whole sequence's, then every window's own (counted from its first frame)
+        offs = [off_l, off_r]
+        for a, b in windows:
+            offs += [off_l[a:b + 2] - off_l[a], off_r[a:b + 2] - off_r[a]]
+        at = np.concatenate([[0], np.cumsum([len(o) for o in offs])])
+        offs_h = torch.empty(int(at[-1]), dtype=torch.int32, pin_memory=True)
+        offs_h.numpy()[:] = np.concatenate(offs)
+        # device arrays of the whole sequence; allocated on the current stream, written by s_in
+        d_in = {"kp_left": torch.empty((NL, 2), dtype=torch.float32, device=dev),
+                "kp_right": torch.empty((NR, 2), dtype=torch.float32, device=dev),
+                "des_left": torch.empty((NL, D), dtype=torch.uint8, device=dev),
+                "des_right": torch.empty((NR, D), dtype=torch.uint8, device=dev)}
+        d_offs = torch.empty(int(at[-1]), dtype=torch.int32, device=dev)
+        rows = {"st_left": (torch.int32, 1), "st_right": (torch.int32, 1), "st_dist": (torch.int32, 1),
+                "st_xyz": (torch.float32, 3), "st_pix_left": (torch.float32, 2), "st_pix_right": (torch.float32, 2),
+                "st_desc": (torch.int32, W), "tm_query": (torch.int32, 1), "tm_train": (torch.int32, 1),
+                "tm_dist": (torch.int32, 1), "tm_mask": (torch.uint8, 1)}
+        t = {name: torch.empty(max(NL, 1) * w, dtype=dt, device=dev) for name, (dt, w) in rows.items()}
+        t["st_count"] = torch.empty(F, dtype=torch.int32, device=dev)
+        t["pose_ransac"] = torch.empty((F - 1) * 12, dtype=torch.float64, device=dev)
+        t["pose_refined"] = torch.empty((F - 1) * 12, dtype=torch.float64, device=dev)
+        t["ransac_info"] = torch.empty((F - 1) * 8, dtype=torch.int32, device=dev)
+        d_samples = None
+        if samples is not None:
+            samples = np.ascontiguousarray(samples, dtype=np.int32)
+            if samples.shape != (F - 1, self.n_iter_max, 4):
+                raise ValueError("samples must have shape (n_frames-1, n_iter_max, 4)")
+            d_samples = kernels.to_device(samples, torch.int32)
+        for x in list(d_in.values()) + [d_offs]:
+            x.record_stream(s_in)
+        # ---- every copy of the inputs, back to back on s_in, an event behind each window's share
+        events = []
+        with torch.cuda.stream(s_in):
+            d_offs.copy_(offs_h, non_blocking=True)
+            for k, (a, b) in enumerate(windows):
+                fa = a if k == 0 else a + 1                 # frame a came with the window before
+                for name, src, off in (("kp_left", kl_h, off_l), ("kp_right", kr_h, off_r),
+                                       ("des_left", dl_h, off_l), ("des_right", dr_h, off_r)):
+                    r0, r1 = int(off[fa]), int(off[b + 1])
+                    if r1 > r0:
+                        d_in[name][r0:r1].copy_(src[r0:r1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(s_in)
+                events.append(ev)
+        # ---- host arrays of the results (page-locked, through torch's caching host allocator)
+        gathers = ("st_desc", "st_pix_left", "st_pix_right")
+        host = {k: torch.empty(v.shape, dtype=v.dtype, pin_memory=True) for k, v in t.items() if k not in gathers}
+        for v in t.values():
+            v.record_stream(s_out)
+        # ---- the argument block: one for the whole sequence (kept with the result), one that
+        # moves from window to window
+        def block(n_frames, nl, nr, first_frame, row_l, row_r, off_at_l, off_at_r, first_stereo):
+            a = self._new_args()
+            a.n_frames, a.n_left_total, a.n_right_total = n_frames, nl, nr
+            a.max_left, a.max_right = max_l, max_r
+            a.desc_bytes, a.desc_stride = D, D
+            a.d_kp_left = d_in["kp_left"].data_ptr() + 8 * row_l
+            a.d_kp_right = d_in["kp_right"].data_ptr() + 8 * row_r
+            a.d_des_left = d_in["des_left"].data_ptr() + D * row_l
+            a.d_des_right = d_in["des_right"].data_ptr() + D * row_r
+            a.d_off_left = d_offs.data_ptr() + 4 * off_at_l
+            a.d_off_right = d_offs.data_ptr() + 4 * off_at_r
+            a.first_pair, a.first_stereo_frame = first_frame, first_stereo
+            for name, (dt, w) in rows.items():
+                setattr(a, "d_" + name, t[name].data_ptr() + t[name].element_size() * w * row_l)
+            a.d_st_count = t["st_count"].data_ptr() + 4 * first_frame
+            a.d_pose_ransac = t["pose_ransac"].data_ptr() + 96 * first_frame
+            a.d_pose_refined = t["pose_refined"].data_ptr() + 96 * first_frame
+            a.d_ransac_info = t["ransac_info"].data_ptr() + 32 * first_frame
+            if d_samples is not None:
+                a.d_samples = d_samples.data_ptr() + 16 * self.n_iter_max * first_frame
+            return a
+        max_l, max_r = int(np.diff(off_l).max()), int(np.diff(off_r).max())
+        blocks = []
+        for k, (a, b) in enumerate(windows):
+            blocks.append(block(b - a + 1, int(off_l[b + 1] - off_l[a]), int(off_r[b + 1] - off_r[a]), a,
+                                int(off_l[a]), int(off_r[a]), int(at[2 + 2 * k]), int(at[3 + 2 * k]),
+                                0 if k == 0 else 1))
+        need = 0
+        for blk in blocks:
+            n = lib.slamhip_frontend_workspace_bytes(C.byref(blk))
+            if n == 0:
+                check(_lib.EUNSUPPORTED, "slamhip_frontend_workspace_bytes")
+            need = max(need, n)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        # ---- passes on the current stream, results down on s_out
+        for k, ((a, b), blk) in enumerate(zip(windows, blocks)):
+            blk.d_workspace, blk.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+            main.wait_event(events[k])
+            check(lib.slamhip_frontend_batch(C.byref(blk), main.cuda_stream), "slamhip_frontend_batch")
+            done = torch.cuda.Event()
+            done.record(main)
+            fa = a if k == 0 else a + 1          # frames whose stereo rows this window has written
+            with torch.cuda.stream(s_out):
+                s_out.wait_event(done)
+                for name, (dt, w) in rows.items():
+                    if name in gathers:
+                        continue
+                    lo, hi = (a, b) if name.startswith("tm_") else (fa, b + 1)
+                    r0, r1 = int(off_l[lo]) * w, int(off_l[hi]) * w
+                    if r1 > r0:
+                        host[name][r0:r1].copy_(t[name][r0:r1], non_blocking=True)
+                host["st_count"][fa:b + 1].copy_(t["st_count"][fa:b + 1], non_blocking=True)
+                for name, w in (("pose_ransac", 12), ("pose_refined", 12), ("ransac_info", 8)):
+                    host[name][a * w:b * w].copy_(t[name][a * w:b * w], non_blocking=True)
+        whole = block(F, NL, NR, 0, 0, 0, 0, int(at[1]), 0)
+        whole.d_workspace, whole.workspace_bytes = self._ws.data_ptr(), self._ws.numel()
+        inputs = FrontendInputs(F, off_l.astype(np.int32), off_r.astype(np.int32), d_offs[:F + 1],
+                                d_offs[int(at[1]):int(at[1]) + F + 1], d_in["kp_left"], d_in["kp_right"],
+                                d_in["des_left"], d_in["des_right"], host=packed)
+        res = FrontendResult(inputs, W, t)
+        res.frame_cross_check = self.frame_cross_check
+        res.args = whole
+        res._keepalive = (d_samples, offs_h, blocks)
+        main.wait_stream(s_in)
+        main.wait_stream(s_out)
+        s_out.synchronize()
+        res._host = {k: v.numpy() for k, v in host.items()}
+        res._pinned_host = host
+        return res
+
+    def _new_args(self) -> FrontendArgs:
+        """An argument block with the camera and the parameters of this front-end filled in."""
+        a = FrontendArgs()
+        for name, src, n in (("K", self.cam.K, 9), ("M_right", self.cam.M_right, 12),
+                             ("P_left", self.cam.P_left, 12), ("P_right", self.cam.P_right, 12)):
+            vals = np.asarray(src, dtype=np.float64).reshape(-1)
+            if vals.size != n:
+                raise ValueError(f"camera.{name} has the wrong shape")
+            setattr(a, name, (C.c_double * n)(*vals.tolist()))
+        a.pixel_thresh, a.disparity_min = self.pixel_thresh, self.disparity_min
+        a.ransac_thresh, a.p_success = self.pixel_thresh, self.p_success
+        a.n_iter_max, a.refine_iters, a.seed = self.n_iter_max, self.refine_iters, self.seed
+        a.stereo_cross_check, a.temporal_cross_check = int(self.stereo_cross_check), int(self.frame_cross_check)
+        return a
+
     def _side_streams(self):
         if getattr(self, "_streams", None) is None:
             self._streams = (torch.cuda.Stream(), torch.cuda.Stream())

@@ -543,6 +543,20 @@ def test_packed_frames_and_chunked_run_equal_the_plain_run():
                 np.testing.assert_array_equal(a[k], b[k], err_msg=f"{k} pair {p}")
                 np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} pair {p} (chunked)")
         np.testing.assert_array_equal(chunked.relative_Rts(), ref.relative_Rts())
+    # the streamed run: one result over the whole sequence, every window's first frame taken
+    # from the window before (no frame's stereo stage runs twice)
+    for chunk in (1, 3, 4, 100):
+        streamed = fe.run_streamed(packed, chunk_pairs=chunk)
+        for f in range(len(frames)):
+            a, c = ref.frame(f), streamed.frame(f)
+            for k in a:
+                np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} frame {f} (streamed, {chunk})")
+        for p in range(len(frames) - 1):
+            a, c = ref.pair(p), streamed.pair(p)
+            for k in a:
+                np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} pair {p} (streamed, {chunk})")
+        np.testing.assert_array_equal(streamed.relative_Rts(), ref.relative_Rts())
+        np.testing.assert_array_equal(streamed.t["st_count"].cpu().numpy(), ref.to_host()["st_count"])
 
 
 @pytest.mark.parametrize("nbytes", [61, 32])
