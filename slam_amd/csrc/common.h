@@ -101,10 +101,10 @@ int knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int nt_to
 // kernel folds the splits itself (the last block to arrive of each query block does) and
 // applies the ratio test when keep != nullptr; otherwise the splits go to `part` for the merge kernel.
 // Descriptor rows as the caller stores them, for the matrix-core kernel's direct read (no packing
-// launch): qp / tp then point at the first row of each array; *_end = one past the last byte.
+// launch): qp / tp then point at the first row of each array.  Rows are at least 16 bytes long
+// (every 16-byte load of the kernel lies inside a row).
 struct RawRows {
   int row_stride, desc_bytes;
-  const uint8_t *q_end, *t_end;
 };
 int mfma_max_split_rows(int W);    // train rows one block may scan (width of its row index)
 void launch_hamming_mfma(int W, int G, int NW, bool best, dim3 grid, hipStream_t st, const uint32_t *qp,

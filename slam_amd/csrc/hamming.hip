@@ -778,8 +778,7 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   if (g_force_splits > 0) s = g_force_splits > kMaxSplits ? kMaxSplits : g_force_splits;
   p.splits = (int)s;
   }
-  p.raw = p.mfma && !prepacked && g_raw_rows != 0 && (long long)nq_total * desc_bytes >= 16 &&
-          (nt_total == 0 || (long long)nt_total * desc_bytes >= 16);   // see below
+  p.raw = p.mfma && !prepacked && g_raw_rows != 0 && desc_bytes >= 16;   // see below
   const bool packs = !prepacked && !p.raw;
   size_t o = 0;
   p.off_qp = o;
@@ -796,8 +795,8 @@ MatchPlan make_plan(int nq_total, int nt_total, int n_pairs, int max_nq, int max
   // against 11.2 at 2048 x 2048, where the call is bound by its launches: small calls fold
   // in the kernel (knob 8: 1 = always, 0 = never, 2 = by size).
   const long long compares = (long long)(max_nq > 0 ? max_nq : 1) * (max_nt > 0 ? max_nt : 1) * (n_pairs > 0 ? n_pairs : 1);
-  // The matrix-core kernel reads unpacked rows itself (unaligned 16-byte loads, tail bytes
-  // masked) unless an array is shorter than one such load.  There is then no packing launch to
+  // The matrix-core kernel reads unpacked rows itself (unaligned 16-byte loads that stay inside
+  // the row, bytes of the neighbouring chunk masked) unless a row is shorter than one such load.  There is then no packing launch to
   // clear the arrival counters, and a fill launch in its place costs what the merge launch
   // costs (2048 x 2048: 7.9 us per call with the merge launch, 10.0 folded behind a fill), so
   // the fold in the kernel is left to calls that pack (knob 9 = 0) or ask for it (knob 8 = 1).
@@ -853,17 +852,13 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   uint2 *part = (uint2 *)(base + p.off_part);
   unsigned *arrivals = (unsigned *)(base + p.off_cnt);
 
-  // The matrix-core kernel reads unpacked rows itself (unaligned 16-byte loads, tail bytes
-  // masked): no packing launch.  Arrays shorter than one 16-byte load keep the packing path.
+  // The matrix-core kernel reads unpacked rows itself (unaligned 16-byte loads inside the row):
+  // no packing launch.  Rows shorter than one 16-byte load keep the packing path.
   slamhip_internal::RawRows raw_rows;
-  const long long q_bytes = (long long)(nq_total - 1) * row_stride + desc_bytes;
-  const long long t_bytes = nt_total > 0 ? (long long)(nt_total - 1) * row_stride + desc_bytes : 0;
   const bool raw = p.raw;
   if (raw) {
     raw_rows.row_stride = row_stride;
     raw_rows.desc_bytes = desc_bytes;
-    raw_rows.q_end = d_query + q_bytes;
-    raw_rows.t_end = d_train ? d_train + t_bytes : nullptr;
     qp = (uint32_t *)d_query;
     tp = (uint32_t *)d_train;
     if (p.fold_in_kernel &&

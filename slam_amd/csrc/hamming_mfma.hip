@@ -123,33 +123,38 @@ __device__ __forceinline__ v4i expand_dword(uint32_t x, uint32_t m8, uint32_t m2
   return o;
 }
 
-// 16 bytes of a descriptor row stored as it came (any alignment): the first `valid` of them
-// (<= 0 .. >= 16) belong to the row, the others read as zero.  `end` = one past the last byte
-// of the array that may be touched (the array is at least 16 bytes long): a load that would
-// reach past it is moved back to end at it, and the bytes shifted down.
-__device__ __forceinline__ uint4 load_raw16(const uint8_t *p, const uint8_t *end, int valid) {
-  const uint8_t *pc = (p + 16 <= end) ? p : end - 16;
-  unsigned __int128 x;
-  __builtin_memcpy(&x, pc, 16);
-  const int back = (int)(p - pc);               // != 0 only in the last rows of the array
-  x >>= 8 * (back < 15 ? back : 15);            // (a chunk wholly behind the row is masked out below)
-  // bytes of the row per dword: valid - 4 j of dword j
-  auto m = [&](int j) {
-    const int nb = valid - 4 * j;
-    return nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : (1u << (8 * nb)) - 1u);
-  };
-  return make_uint4((uint32_t)x & m(0), (uint32_t)(x >> 32) & m(1), (uint32_t)(x >> 64) & m(2),
-                    (uint32_t)(x >> 96) & m(3));
-}
+// Chunk `off / 16` of a descriptor row stored as it came (any alignment, `nbytes` >= 16 bytes
+// long): bytes [off, off + 16) of the row, the ones behind its end reading as zero.  The 16-byte
+// load is moved back to start at min(off, nbytes - 16), so it never leaves the row (and so never
+// the array), and the bytes it then brings along from the chunk before are masked off: the
+// chunk's own bytes sit at the high end of the result.  Query and train rows are fetched by this
+// one function, so a descriptor bit lands on the same k position of both operands.
+struct RawChunk {
+  int start;          // byte offset of the load inside the row
+  uint32_t m[4];      // the chunk's own bytes, per dword of the load
+  __device__ __forceinline__ RawChunk(int off, int nbytes) {
+    start = min(off, nbytes - 16);
+    const int skip = min(off - start, 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nb = skip - 4 * j;
+      m[j] = nb >= 4 ? 0u : (nb <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nb));
+    }
+  }
+  __device__ __forceinline__ uint4 load(const uint8_t *row) const {
+    uint4 x;
+    __builtin_memcpy(&x, row + start, 16);
+    return make_uint4(x.x & m[0], x.y & m[1], x.z & m[2], x.w & m[3]);
+  }
+};
 
 // swizzle term of a row (XORed into the 16-byte chunk index)
 template <int W> __device__ __forceinline__ int row_swizzle(int row) {
   return W == 8 ? ((row >> 1) & 7) : (row & 15);
 }
 
-// RAW: qp / tp are the caller's descriptor rows as they are (desc_bytes long, row_stride apart,
-// any alignment; q_end / t_end one past the last byte of each array) instead of rows packed to W
-// dwords: no packing launch in front.
+// RAW: qp / tp are the caller's descriptor rows as they are (desc_bytes >= 16 long, row_stride
+// apart, any alignment) instead of rows packed to W dwords: no packing launch in front.
 template <int W, int G, bool BEST, int NW, bool RAW>
 __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_kernel(
     const uint32_t *__restrict__ qp, const uint32_t *__restrict__ tp,
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     const int32_t *__restrict__ out_off, int nq_single, int nt_single, int nq_total,
     uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2,
     unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep, int row_stride, int desc_bytes,
-    const uint8_t *__restrict__ q_end, const uint8_t *__restrict__ t_end, int xq, int xs, int xp) {
+    int xq, int xs, int xp) {
   using GEO = Geo<W, NW>;
   constexpr int kThreads = GEO::NT;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
@@ -226,11 +231,9 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
   for (int g = 0; g < G; ++g) {
     qrow[g] = qblk + (wave * G + g) * 32 + r;
     if (RAW) {
-      const uint8_t *src = reinterpret_cast<const uint8_t *>(qp) + (size_t)(q0 + min(qrow[g], nq - 1)) * row_stride +
-                           4 * h * KS;
+      const uint8_t *src = reinterpret_cast<const uint8_t *>(qp) + (size_t)(q0 + min(qrow[g], nq - 1)) * row_stride;
 #pragma unroll
-      for (int k = 0; k < KS / 4; ++k)
-        qraw[g][k] = load_raw16(src + 16 * k, q_end, desc_bytes - 4 * h * KS - 16 * k);
+      for (int k = 0; k < KS / 4; ++k) qraw[g][k] = RawChunk(4 * h * KS + 16 * k, desc_bytes).load(src);
     } else {
       const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W + h * KS);
 #pragma unroll
@@ -277,15 +280,15 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
       for (int j = 0; j < 4; ++j) u_dst[k][j] = (row * CPR + ((4 * c4 + j) ^ f)) * 16;
     }
     const uint32_t *tbase = tp + (size_t)t0 * W + 4 * ((tid % (W / 4)));
-    const uint8_t *traw = reinterpret_cast<const uint8_t *>(tp) + (size_t)t0 * row_stride + 16 * (tid % (W / 4));
-    const int tvalid = desc_bytes - 16 * (tid % (W / 4));     // bytes of the row in this thread's chunks
+    const uint8_t *traw = reinterpret_cast<const uint8_t *>(tp) + (size_t)t0 * row_stride;
+    const RawChunk tchunk(16 * (tid % (W / 4)), RAW ? desc_bytes : 16);   // this thread's chunk of every row it stages
     char *const lbase = reinterpret_cast<char *>(lds);
     uint32_t ux[PIECES];
     auto load_stage = [&](int stage_begin) {
 #pragma unroll
       for (int k = 0; k < UNITS; ++k) {
         const int grow = min(stage_begin + u_row[k], r_end - 1);   // rows past the end: the last row again
-        const uint4 v = RAW ? load_raw16(traw + (size_t)grow * row_stride, t_end, tvalid)
+        const uint4 v = RAW ? tchunk.load(traw + (size_t)grow * row_stride)
                             : *reinterpret_cast<const uint4 *>(tbase + (size_t)grow * W);
         ux[4 * k + 0] = v.x; ux[4 * k + 1] = v.y; ux[4 * k + 2] = v.z; ux[4 * k + 3] = v.w;
       }
@@ -322,9 +325,12 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     v4i a[KS];
     v16f cin;
     float tprev[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) tprev[g] = -1.0f;
     constexpr bool PIPE = W < 32;   // 32-word rows: the fragments alone are 64 registers, no room to run ahead
     auto tile_step = [&](int tile, const char *cur_a, const char *cur_c, const char *pf_a, const char *pf_c,
-                         int pf_tile, char *st_dst, v16f (&acc)[G], const v16f (&old)[G]) {
+                         int pf_tile, char *st_dst, v16f (&acc)[G], const v16f (&old)[G], int ct_buf,
+                         int ct_begin) {
       if (!PIPE) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const v4i *>(cur_a + tile * 32 * CPR * 16 + aoff[s]);
@@ -362,6 +368,14 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
             b1[g] = kmax3(b1[g], x, y);
           }
         }
+        // the slice's results are pinned to this k-step (left to itself the compiler gathers the
+        // folds of several k-steps behind the stage's barrier, where no matrix instruction
+        // runs beside them)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (BEST) asm volatile("" : "+v"(b1[g]));
+          else asm volatile("" : "+v"(b1[g]), "+v"(b2[g]), "+v"(tprev[g]));
+        }
 #else
         if (s == 0)
 #pragma unroll
@@ -369,6 +383,7 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
 #endif
         // staging: piece p of the next stage in k-step p * SLOTS / PIECES of this stage
         const int slot = tile * KS + s;
+        if (slot == 1) store_ctab(ct_buf, ct_begin);   // the next stage's C_in table (read behind the barrier)
         if (tile < T - 1) {
 #pragma unroll
           for (int p = 0; p < PIECES; ++p)
@@ -407,19 +422,18 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
       const char *ncbase = lbase + coff + (buf ^ 1) * (kThreads * 4);
       // the next stage (in registers since the stage before) goes to the other buffer piece by
       // piece during tiles 0 .. T-2; nobody reads that buffer before the barrier
-      store_ctab(buf ^ 1, sb + R);
 #pragma unroll
       for (int tile = 0; tile < T; tile += 2) {
-        tile_step(tile, sbase, cbase, sbase, cbase, tile + 1, nbase, accA, accB);
+        tile_step(tile, sbase, cbase, sbase, cbase, tile + 1, nbase, accA, accB, buf ^ 1, sb + R);
         if (tile + 2 == T) {
           // every piece of the next stage is on its way to LDS: meet the other waves (after
           // the barrier the next stage may be read and this one is no longer needed), and
           // ask for the stage after it (rows clamped when there is none)
           __syncthreads();
           load_stage(sb + 2 * R);
-          tile_step(tile + 1, sbase, cbase, nbase, ncbase, 0, nbase, accB, accA);
+          tile_step(tile + 1, sbase, cbase, nbase, ncbase, 0, nbase, accB, accA, buf ^ 1, sb + R);
         } else {
-          tile_step(tile + 1, sbase, cbase, sbase, cbase, tile + 2, nbase, accB, accA);
+          tile_step(tile + 1, sbase, cbase, sbase, cbase, tile + 2, nbase, accB, accA, buf ^ 1, sb + R);
         }
       }
     }
@@ -555,11 +569,11 @@ void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, c
   if (raw != nullptr)
     hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, true>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,
                        q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep,
-                       raw->row_stride, raw->desc_bytes, raw->q_end, raw->t_end, xq, xs, xp);
+                       raw->row_stride, raw->desc_bytes, xq, xs, xp);
   else
     hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, false>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,
                        q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio, keep, 0,
-                       0, nullptr, nullptr, xq, xs, xp);
+                       0, xq, xs, xp);
 }
 
 }  // namespace
