@@ -136,10 +136,8 @@ struct RawChunk {
     start = min(off, nbytes - 16);
     const int skip = min(off - start, 16);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nb = skip - 4 * j;
-      m[j] = nb >= 4 ? 0u : (nb <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nb));
-    }
+    for (int j = 0; j < 4; ++j)   // dword j loses its low min(max(skip - 4 j, 0), 4) bytes
+      m[j] = (uint32_t)(0xFFFFFFFFull << (8 * min(max(skip - 4 * j, 0), 4)));
   }
   __device__ __forceinline__ uint4 load(const uint8_t *row) const {
     uint4 x;
@@ -164,6 +162,12 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     uint2 *__restrict__ partial, int32_t *__restrict__ idx2, int32_t *__restrict__ dist2,
     unsigned *__restrict__ arrivals, double ratio, uint8_t *__restrict__ keep, int row_stride, int desc_bytes,
     int xq, int xs, int xp) {
+  // Every argument is asked for at once: left alone, the compiler fetches them in three or four
+  // dependent groups behind the early exits, one scalar-memory round trip each, in front of the
+  // first descriptor load.
+  asm volatile("" ::"s"(qp), "s"(tp), "s"(q_off), "s"(q_cnt), "s"(t_off), "s"(t_cnt), "s"(out_off), "s"(nq_single),
+               "s"(nt_single), "s"(nq_total), "s"(partial), "s"(idx2), "s"(dist2), "s"(arrivals), "s"(keep),
+               "s"(row_stride), "s"(desc_bytes), "s"(xq), "s"(xs), "s"(xp), "s"(gridDim.x), "s"(gridDim.y));
   using GEO = Geo<W, NW>;
   constexpr int kThreads = GEO::NT;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
