@@ -50,6 +50,7 @@ namespace {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v8i __attribute__((ext_vector_type(8)));
 typedef float v16f __attribute__((ext_vector_type(16)));
+template <bool B> struct IntC { static constexpr bool value = B; };
 
 constexpr int kKeyShift = 21;
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
@@ -123,6 +124,14 @@ __device__ __forceinline__ v4i expand_dword(uint32_t x, uint32_t m8, uint32_t m2
   return o;
 }
 
+// 16 bytes at any alignment (global memory or LDS)
+__device__ __forceinline__ uint4 load16(const uint8_t *p) {
+  uint4 x;
+  __builtin_memcpy(&x, p, 16);
+  return x;
+}
+__device__ __forceinline__ void store16(uint8_t *p, uint4 v) { __builtin_memcpy(p, &v, 16); }
+
 // Chunk `off / 16` of a descriptor row stored as it came (any alignment, `nbytes` >= 16 bytes
 // long): bytes [off, off + 16) of the row, the ones behind its end reading as zero.  The 16-byte
 // load is moved back to start at min(off, nbytes - 16), so it never leaves the row (and so never
@@ -139,7 +148,7 @@ struct RawChunk {
     for (int j = 0; j < 4; ++j)   // dword j loses its low min(max(skip - 4 j, 0), 4) bytes
       m[j] = (uint32_t)(0xFFFFFFFFull << (8 * min(max(skip - 4 * j, 0), 4)));
   }
-  __device__ __forceinline__ uint4 load(const uint8_t *row) const {
+  __device__ __forceinline__ uint4 load(const uint8_t *row) const {   // global memory or LDS
     uint4 x;
     __builtin_memcpy(&x, row + start, 16);
     return make_uint4(x.x & m[0], x.y & m[1], x.z & m[2], x.w & m[3]);
@@ -165,9 +174,11 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
   // Every argument is asked for at once: left alone, the compiler fetches them in three or four
   // dependent groups behind the early exits, one scalar-memory round trip each, in front of the
   // first descriptor load.
+#if defined(__HIP_DEVICE_COMPILE__)
   asm volatile("" ::"s"(qp), "s"(tp), "s"(q_off), "s"(q_cnt), "s"(t_off), "s"(t_cnt), "s"(out_off), "s"(nq_single),
                "s"(nt_single), "s"(nq_total), "s"(partial), "s"(idx2), "s"(dist2), "s"(arrivals), "s"(keep),
                "s"(row_stride), "s"(desc_bytes), "s"(xq), "s"(xs), "s"(xp), "s"(gridDim.x), "s"(gridDim.y));
+#endif
   using GEO = Geo<W, NW>;
   constexpr int kThreads = GEO::NT;
   constexpr int KS = GEO::KS, CPR = GEO::CPR, R = GEO::R, SH = GEO::SH, MASK = GEO::MASK;
@@ -221,7 +232,10 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
 #endif
 #if (SLAMHIP_ABLATE & 64)  // timing experiment: start and end of every block in 100 MHz ticks, behind dist2
   const unsigned span0 = (unsigned)__builtin_amdgcn_s_memrealtime();
-  unsigned span_prologue = span0, span_loop = span0;
+  unsigned span_prologue = span0, span_loop = span0, span_staged = span0;
+#endif
+#if (SLAMHIP_ABLATE & 64) && defined(__HIP_DEVICE_COMPILE__)
+  unsigned span_t2 = span0, span_t3 = span0;
 #endif
   const uint32_t m8 = 0x88888888u, m2 = 0x22222222u;
 
@@ -232,35 +246,51 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
   int qrow[G];
   uint4 qraw[G][KS / 4];
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
-    qrow[g] = qblk + (wave * G + g) * 32 + r;
-    if (RAW) {
-      const uint8_t *src = reinterpret_cast<const uint8_t *>(qp) + (size_t)(q0 + min(qrow[g], nq - 1)) * row_stride;
+  for (int g = 0; g < G; ++g) qrow[g] = qblk + (wave * G + g) * 32 + r;
+  // The block's query rows reach the lanes in one of two ways.  Directly: lane (r, h) loads its
+  // row's chunks itself -- 32 rows a row pitch apart per request, which the memory pipeline of a
+  // CU works through at a fifth of its rate for consecutive addresses, and every CU of the launch
+  // does this at the same moment.  Or, when the rows fit (kQueryCopies requests per thread), as a
+  // plain copy of the rows' bytes into LDS (consecutive lanes, consecutive 16 bytes; the image
+  // lies in the second stage buffer, which nobody writes before the second barrier below), from
+  // where each lane then picks its chunks.
+  constexpr int kQueryCopies = 4;
+  const int q_pitch = RAW ? row_stride : 4 * W, q_bytes = RAW ? desc_bytes : 4 * W;
+  const int q_rows = min(NW * 32 * G, nq - qblk);
+  const int q_len = (q_rows - 1) * q_pitch + q_bytes;             // bytes from the block's first row to its last row's end
+  const bool q_via_lds = q_len <= kQueryCopies * kThreads * 16;   // block-uniform
+  const uint8_t *const q_base = reinterpret_cast<const uint8_t *>(qp) + (size_t)(q0 + qblk) * q_pitch;
+  uint8_t *const q_image = reinterpret_cast<uint8_t *>(lds + kStageSlots);
+  uint4 qcopy[kQueryCopies];
+  auto copy_offset = [&](int j) { return min((j * kThreads + (int)threadIdx.x) * 16, q_len - 16); };   // pieces past the end: the last one again
+  auto load_query_copy = [&]() {
 #pragma unroll
-      for (int k = 0; k < KS / 4; ++k) qraw[g][k] = RawChunk(4 * h * KS + 16 * k, desc_bytes).load(src);
-    } else {
-      const uint4 *src = reinterpret_cast<const uint4 *>(qp + (size_t)(q0 + min(qrow[g], nq - 1)) * W + h * KS);
+    for (int j = 0; j < kQueryCopies; ++j) qcopy[j] = load16(q_base + copy_offset(j));
+  };
+  auto store_query_copy = [&]() {
 #pragma unroll
-      for (int k = 0; k < KS / 4; ++k) qraw[g][k] = src[k];
-    }
-  }
+    for (int j = 0; j < kQueryCopies; ++j) store16(q_image + copy_offset(j), qcopy[j]);
+  };
+  // chunk k (16 bytes: four k-steps) of every group's query rows, from the image or from memory
+  auto load_queries = [&](int k, const uint8_t *rows) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+      qraw[g][k] = RawChunk(4 * h * KS + 16 * k, q_bytes).load(rows + (size_t)(min(qrow[g], nq - 1) - qblk) * q_pitch);
+  };
   const int scale_t = 127 + SH - 1, scale_q = 127;   // E8M0: 2^(SH-1) and 1
 
   float b1[G], b2[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) b1[g] = b2[g] = -1.0f;             // negative: no key yet
-  auto expand_queries = [&]() {
+  // k-step s of every group's B fragments from the raw query dwords
+  auto expand_query_step = [&](int s) {
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int k = 0; k < KS / 4; ++k) {
-        const uint32_t x[4] = {qraw[g][k].x, qraw[g][k].y, qraw[g][k].z, qraw[g][k].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const v4i e = expand_dword(x[j], m8, m2);
-          bq[g][4 * k + j] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
-        }
-      }
+    for (int g = 0; g < G; ++g) {
+      const uint4 v = qraw[g][s / 4];
+      const uint32_t x = s % 4 == 0 ? v.x : (s % 4 == 1 ? v.y : (s % 4 == 2 ? v.z : v.w));
+      const v4i e = expand_dword(x, m8, m2);
+      bq[g][s] = v8i{e[0], e[1], e[2], e[3], 0, 0, 0, 0};
+    }
   };
 
   if (r_begin < r_end) {
@@ -332,9 +362,13 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
 #pragma unroll
     for (int g = 0; g < G; ++g) tprev[g] = -1.0f;
     constexpr bool PIPE = W < 32;   // 32-word rows: the fragments alone are 64 registers, no room to run ahead
+    // `first` (a compile-time flag): the very first tile of the block.  It has no tile before it to
+    // fold; its k-steps expand the next k-step's query fragments instead, so the block's first
+    // matrix instruction waits for one k-step of the queries and not for all of them.
     auto tile_step = [&](int tile, const char *cur_a, const char *cur_c, const char *pf_a, const char *pf_c,
                          int pf_tile, char *st_dst, v16f (&acc)[G], const v16f (&old)[G], int ct_buf,
-                         int ct_begin) {
+                         int ct_begin, auto first) {
+      constexpr bool FIRST = decltype(first)::value;
       if (!PIPE) {
 #pragma unroll
         for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const v4i *>(cur_a + tile * 32 * CPR * 16 + aoff[s]);
@@ -357,6 +391,9 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
           a[s] = *reinterpret_cast<const v4i *>(pf_a + pf_tile * 32 * CPR * 16 + aoff[s]);
           if (s == 0) cin = read_cin(pf_c, pf_tile);
         }
+        if (FIRST) {
+          if (s + 1 < KS) expand_query_step(s + 1);
+        } else {
         // fold: the 8 key pairs of `old` spread over the KS steps
 #if !(SLAMHIP_ABLATE & 1)
 #pragma unroll
@@ -385,6 +422,7 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
 #pragma unroll
           for (int g = 0; g < G; ++g) asm volatile("" ::"v"(old[g]));
 #endif
+        }
         // staging: piece p of the next stage in k-step p * SLOTS / PIECES of this stage
         const int slot = tile * KS + s;
         if (slot == 1) store_ctab(ct_buf, ct_begin);   // the next stage's C_in table (read behind the barrier)
@@ -398,16 +436,51 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     };
 
     v16f accA[G], accB[G];
+    // Order of the block's first requests (they come back in this order, and every block of the
+    // launch asks at the same moment): the first stage's rows, which all waves wait for at the
+    // first barrier, then the query chunks in the order the first tile uses them.
+#if (SLAMHIP_ABLATE & 64) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" ::"v"(aoff[KS - 1]), "v"(u_dst[0][3]));
+    span_t2 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
+    load_stage(r_begin);
+    if (q_via_lds) {
+      load_query_copy();
+    } else {
 #pragma unroll
-    for (int g = 0; g < G; ++g)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) accB[g][i] = -1.0f;             // nothing to fold before the first tile
-    load_stage(r_begin);                       // in flight while the queries are expanded
-    expand_queries();
+      for (int k = 0; k < KS / 4; ++k) load_queries(k, q_base);
+    }
 #pragma unroll
     for (int p = 0; p < PIECES; ++p) store_piece(lbase, p);
+#if (SLAMHIP_ABLATE & 64) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    span_t3 = (unsigned)__builtin_amdgcn_s_memrealtime();
+#endif
     store_ctab(0, r_begin);
+    if (q_via_lds) {
+      store_query_copy();
+      __syncthreads();                         // the image is whole
+#pragma unroll
+      for (int k = 0; k < KS / 4; ++k) load_queries(k, q_image);
+    }
     load_stage(r_begin + R);
+    expand_query_step(0);                      // the other k-steps' fragments are expanded inside the first tile
+#if (SLAMHIP_ABLATE & 64) && defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    span_staged = (unsigned)__builtin_amdgcn_s_memrealtime();
+    if (lane == 0 && blockIdx.z == 0 && gridDim.x * gridDim.y <= 256) {   // every wave: its start and its arrival at the barrier
+      int *o = dist2 + 2 * (size_t)nq_total + 8 * 256 + 16 * (blockIdx.y * gridDim.x + blockIdx.x) + 2 * wave;
+      o[0] = (int)span0;
+      o[1] = (int)span_staged;
+      if ((wave & 3) == 0) {      // waves 0 and 4 (the two waves of one SIMD): the steps in between
+        int *o2 = dist2 + 2 * (size_t)nq_total + 8 * 256 + 16 * 256 + 8 * (blockIdx.y * gridDim.x + blockIdx.x) + (wave & 4);
+        o2[0] = (int)span0;
+        o2[1] = (int)span_t2;
+        o2[2] = (int)span_t3;
+        o2[3] = (int)span_staged;
+      }
+    }
+#endif
     __syncthreads();
 #if (SLAMHIP_ABLATE & 64)
     span_prologue = (unsigned)__builtin_amdgcn_s_memrealtime();
@@ -417,9 +490,9 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
       for (int s = 0; s < KS; ++s) a[s] = *reinterpret_cast<const v4i *>(lbase + aoff[s]);
       cin = read_cin(lbase + coff, 0);
     }
-    int buf = 0;
-    // Every stage runs whole: rows past the end carry a C_in that can never win.
-    for (int sb = r_begin; sb < r_end; sb += R, buf ^= 1) {
+    // Every stage runs whole: rows past the end carry a C_in that can never win.  The first
+    // stage is written out on its own (its first tile differs), the others loop.
+    auto run_stage = [&](int sb, int buf, auto first) {
       const char *sbase = lbase + buf * (kStageSlots * 16);
       const char *cbase = lbase + coff + buf * (kThreads * 4);
       char *nbase = lbase + (buf ^ 1) * (kStageSlots * 16);
@@ -428,19 +501,25 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
       // piece during tiles 0 .. T-2; nobody reads that buffer before the barrier
 #pragma unroll
       for (int tile = 0; tile < T; tile += 2) {
-        tile_step(tile, sbase, cbase, sbase, cbase, tile + 1, nbase, accA, accB, buf ^ 1, sb + R);
+        if (tile == 0)
+          tile_step(tile, sbase, cbase, sbase, cbase, tile + 1, nbase, accA, accB, buf ^ 1, sb + R, first);
+        else
+          tile_step(tile, sbase, cbase, sbase, cbase, tile + 1, nbase, accA, accB, buf ^ 1, sb + R, IntC<false>{});
         if (tile + 2 == T) {
           // every piece of the next stage is on its way to LDS: meet the other waves (after
           // the barrier the next stage may be read and this one is no longer needed), and
           // ask for the stage after it (rows clamped when there is none)
           __syncthreads();
           load_stage(sb + 2 * R);
-          tile_step(tile + 1, sbase, cbase, nbase, ncbase, 0, nbase, accB, accA, buf ^ 1, sb + R);
+          tile_step(tile + 1, sbase, cbase, nbase, ncbase, 0, nbase, accB, accA, buf ^ 1, sb + R, IntC<false>{});
         } else {
-          tile_step(tile + 1, sbase, cbase, sbase, cbase, tile + 2, nbase, accB, accA, buf ^ 1, sb + R);
+          tile_step(tile + 1, sbase, cbase, sbase, cbase, tile + 2, nbase, accB, accA, buf ^ 1, sb + R, IntC<false>{});
         }
       }
-    }
+    };
+    run_stage(r_begin, 0, IntC<true>{});
+    int buf = 1;
+    for (int sb = r_begin + R; sb < r_end; sb += R, buf ^= 1) run_stage(sb, buf, IntC<false>{});
 #if (SLAMHIP_ABLATE & 64)
     span_loop = (unsigned)__builtin_amdgcn_s_memrealtime();
 #endif
@@ -546,6 +625,8 @@ __global__ __launch_bounds__(64 * NW, G == 4 ? 1 : 8 / NW) void hamming_mfma_ker
     o[3] = (int)hw;
     o[4] = (int)span_prologue;
     o[5] = (int)span_loop;
+    o[6] = 0;
+    o[7] = (int)span_staged;
   }
 #endif
 #if (SLAMHIP_ABLATE & 32)  // slots 38 / 39: the wave's lifetime in shader cycles and in 100 MHz ticks

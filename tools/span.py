@@ -12,7 +12,7 @@ n = int(sys.argv[3]) if len(sys.argv) > 3 else 8192
 qn, tn = matcher_workload(n, n, 61, seed=3)
 q = kernels.to_device(qn, torch.uint8); t = kernels.to_device(tn, torch.uint8)
 _lib.lib.slamhip_tune(0, variant); _lib.lib.slamhip_tune(1, splits)
-extra = 4096
+extra = 8192
 i2 = torch.zeros(2 * n + extra, dtype=torch.int32, device="cuda")
 d2 = torch.zeros(2 * n + extra, dtype=torch.int32, device="cuda")
 need = _lib.lib.slamhip_hamming_knn2_workspace_bytes(n, n, 1, n, n, 61)
@@ -42,6 +42,22 @@ print(f"event-timed kernel {ms.value / k * 1e3:.2f} us; blocks {nb}: start sprea
 pro, loop = (rec[:, 4] - rec[:, 0]) / 100, (rec[:, 5] - rec[:, 4]) / 100
 print(f"wave 0 of a block: prologue (to the first barrier) median {np.median(pro):.2f} us, stage loop {np.median(loop):.2f} us, "
       f"epilogue {np.median((rec[:, 1] - rec[:, 5]) / 100):.2f} us")
+if rec[:, 6].any():
+    print(f"  of the prologue: queries fetched and expanded after {np.median((rec[:, 6] - rec[:, 0]) / 100):.2f} us, first stage "
+          f"in LDS after {np.median((rec[:, 7] - rec[:, 0]) / 100):.2f} us, barrier passed after {np.median(pro):.2f} us")
+if nb <= 256 and variant == 18:
+    w = tail[8 * 256:8 * 256 + 16 * nb].reshape(nb, 8, 2)
+    if w.any():
+        w0 = rec[:, 0][:, None]
+        print("  per wave of a block, medians over blocks (us after the block's wave 0 started): start",
+              np.round(np.median((w[:, :, 0] - w0) / 100, axis=0), 2), " its stage pieces in LDS",
+              np.round(np.median((w[:, :, 1] - w0) / 100, axis=0), 2))
+    w2 = tail[8 * 256 + 16 * 256:8 * 256 + 16 * 256 + 8 * nb].reshape(nb, 2, 4)
+    if w2.any():
+        for i, name in ((0, "wave 0"), (1, "wave 4")):
+            d = (w2[:, i, :] - w2[:, i, :1]) / 100
+            print(f"  {name}: set-up done (before the first row request) {np.median(d[:, 1]):.2f}, its stage pieces stored "
+                  f"{np.median(d[:, 2]):.2f}, first query fragments expanded {np.median(d[:, 3]):.2f} us after its start")
 life = (en - st) / 100
 xcc = rec[:, 2] & 0xF
 hw = rec[:, 3]
