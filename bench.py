@@ -67,8 +67,9 @@ OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
 # 8 / 16 / 32 dwords.  Peak: MI355X block-scaled FP4 MFMA, dense (no sparsity).
 MFMA_PEAK_FLOPS = 10.0e15
 # HBM-side bytes per matrix-core top-2 launch, same recipe (profiles/r3/pmc_matcher8k.txt, final build:
-# FETCH_SIZE 2274 KB x2 + WRITE_SIZE 1024 KB; profiles/r2/pmc_matcher8k_mfma.txt had 2276).
-PMC_TRAFFIC_BYTES_MFMA = (2274 * 2 + 1024) * 1024
+# FETCH_SIZE 2294 KB x2 + WRITE_SIZE 1024 KB; profiles/r2/pmc_matcher8k_mfma.txt had 2276).  The reads are the
+# rows arriving in eight L2s, one per XCD: each holds two query blocks' rows (62 KB) and every train row (500 KB).
+PMC_TRAFFIC_BYTES_MFMA = (2294 * 2 + 1024) * 1024
 
 
 def flop_per_compare(desc_bytes, issued=False):
