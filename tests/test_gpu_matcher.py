@@ -384,7 +384,9 @@ def test_facade_errors_like_reference():
 
 @pytest.mark.parametrize("desc_bytes,stride,offset", [(61, 61, 0), (61, 61, 1), (61, 67, 3), (32, 32, 2),
                                                       (64, 64, 1), (64, 70, 0), (1, 1, 0), (5, 9, 3),
-                                                      (128, 128, 3), (100, 101, 2), (33, 40, 1), (17, 17, 0), (49, 49, 5), (16, 16, 1), (15, 15, 0)])
+                                                      (128, 128, 3), (100, 101, 2), (33, 40, 1), (17, 17, 0), (49, 49, 5), (16, 16, 1), (15, 15, 0),
+                                                      # row pitches too wide for the query rows' copy through LDS
+                                                      (61, 200, 2), (32, 150, 1), (128, 300, 0), (16, 1000, 3)])
 def test_rows_at_any_alignment_and_stride(desc_bytes, stride, offset):
     """Through the C ABI with rows at an arbitrary byte offset and stride (the row
     packer fetches aligned dwords and funnel-shifts): results equal the oracle.
