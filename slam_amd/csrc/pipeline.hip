@@ -1532,7 +1532,7 @@ struct Layout {
   bool raw;                    // the stereo matcher reads the caller's descriptor rows: no packed copy
 };
 
-constexpr int kInPlaceRows = 4096;   // features per image up to which the stereo matcher reads unpacked rows
+constexpr int kInPlaceRows = 1 << 20;  // features per image up to which the stereo matcher reads unpacked rows (no limit in practice)
 constexpr int kSmallCallFrames = 3;  // frames up to which a front-end call runs its stages as fused launches
 constexpr int kSmallCallRows = 4096; // ... and features per image
 
@@ -1546,10 +1546,10 @@ Layout make_layout(const slamhip_frontend_args *a) {
   const int F = a->n_frames > 0 ? a->n_frames : 1;
   // frames whose stereo stage this call runs (the others' outputs are in place: first_stereo_frame)
   const int Fs = (a->first_stereo_frame > 0 && a->first_stereo_frame < F) ? F - a->first_stereo_frame : F;
-  // In place where the matcher's kernel can and a frame is a few query blocks: every one of them
-  // reads the frame's train rows again, and the unaligned, masked read costs more than the aligned
-  // one (measured per pass, in place against packed first: 500 frames of 1500 features 0.755 /
-  // 0.779 ms, 250 of 3000 1.031 / 1.040, 100 of 2000-8000 1.67 / 1.65).
+  // In place wherever the matcher's kernel can read the rows as they are (no packed copy of the
+  // descriptors, no packing launch).  Measured per pass, in place against packed first, with the
+  // loader that needs no shift: 60 frames of 2000-8000 features 0.763 / 0.773 ms, 100 of 5000
+  // 0.804 / 0.801, 30 of 8000 0.789 / 0.797.
   L.raw = a->max_left <= kInPlaceRows && a->max_right <= kInPlaceRows &&
           slamhip_internal::knn2_reads_raw(a->n_left_total, a->n_right_total, Fs, a->max_left,
                                            a->max_right, a->desc_bytes) &&

@@ -135,6 +135,47 @@ def test_500_frames_of_1500_features():
             assert got["iterations"] == ref["iterations"]
 
 
+def test_frames_of_2000_to_8000_features():
+    """The feature counts the benchmark envelope names (2000-8000 per image, a ragged batch): every
+    frame's stereo matches and every pair's temporal matches equal the C/OpenMP restatement's, the
+    triangulated points agree to 1e-4 relative, and with the same idx4 samples a pair with the same
+    winner ran the same number of iterations.  (The stereo matcher reads these frames' descriptor
+    rows where the caller left them.)"""
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    cam = CameraModel.kitti_like()
+    F, n_iter = 6, 600
+    seq, frames = _frames(cam, F, (2000, 8000), seed=77)
+    assert max(len(f[0]) for f in frames) > 4096
+    fe = TrackingFrontend(cam, n_iter_max=n_iter)
+    inputs = fe.upload(frames)
+    st_count = TrackingFrontend(cam, n_iter_max=1).run(inputs).to_host()["st_count"][:F].copy()
+    rng = np.random.default_rng(3)
+    samples = np.stack([_distinct_samples(rng, int(st_count[p]), n_iter) for p in range(F - 1)])
+    h = fe.run(inputs, samples=samples).to_host()
+    c = fc.frontend_run(cam, frames, samples=samples, n_iter_max=n_iter)
+    off = inputs.off_left
+    info = h["ransac_info"].reshape(-1, 8)[:F - 1]
+    np.testing.assert_array_equal(c["st_count"][:F], st_count)
+    assert st_count.min() > 500
+    for key_c, key_d in (("st_left", "st_left"), ("st_right", "st_right"), ("st_dist", "st_dist"),
+                         ("tm_q", "tm_query"), ("tm_t", "tm_train"), ("tm_d", "tm_dist")):
+        cnt = st_count if key_c.startswith("st") else c["tm_count"]
+        for f in range(F if key_c.startswith("st") else F - 1):
+            sl = slice(off[f], off[f] + cnt[f])
+            np.testing.assert_array_equal(h[key_d][sl], c[key_c][sl], err_msg=f"{key_c} frame {f}")
+    xyz_d, xyz_c = h["st_xyz"].reshape(-1, 3), c["st_xyz"]
+    for f in range(F):
+        sl = slice(off[f], off[f] + st_count[f])
+        assert (np.abs(xyz_d[sl] - xyz_c[sl]) <= 1e-4 * np.abs(xyz_c[sl]).max(axis=1, keepdims=True)).all()
+    same = info[:, 0] == c["info"][:F - 1, 0]
+    assert same.sum() >= F - 2, same
+    for p in np.flatnonzero(same):
+        sl = slice(off[p], off[p] + info[p, 5])
+        assert info[p, 2] == c["info"][p, 2], p
+        assert (h["tm_mask"][sl] != c["mask"][sl]).sum() <= 1
+
+
 def test_all_pairs_of_270_keyframes():
     from slam_amd import CameraModel
     from slam_amd.backend.optimizers.loop_verify import PairVerifier
