@@ -20,9 +20,13 @@
 //   block  = NW waves (4, or 8 for one large pair); wave = G groups of 32 queries whose
 //            expanded rows stay in registers (B operand) for the whole scan
 //   grid   = (query blocks, train splits, pairs), as the popcount kernel
+//   queries = the block's query rows are copied into LDS as they lie in memory (consecutive
+//            lanes, consecutive 16 bytes) and each lane picks its row's chunks from there; the
+//            fragments of the first k-step are expanded in front of the first tile, the others
+//            inside it (it has no earlier tile to fold)
 //   stage  = R train rows: loaded 16 bytes per thread, either from rows packed to W dwords or
-//            from the caller's rows as they are (RAW: unaligned loads, bytes behind the row
-//            masked off), expanded to FP4 on the fly (one dword -> four dwords: bit plane p of
+//            from the caller's rows as they are (RAW: unaligned loads that stay inside the row,
+//            bytes of the neighbouring chunk masked off), expanded to FP4 on the fly (one dword -> four dwords: bit plane p of
 //            the dword, (x << (3 - p)) & 0x88888888 | 0x22222222), written to LDS in a
 //            16-byte-slot XOR swizzle that makes the A-fragment ds_read_b128 of 32 rows
 //            conflict-free; two buffers, one barrier per stage.  A table of the stage's C_in
