@@ -557,6 +557,16 @@ def test_packed_frames_and_chunked_run_equal_the_plain_run():
                 np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} pair {p} (streamed, {chunk})")
         np.testing.assert_array_equal(streamed.relative_Rts(), ref.relative_Rts())
         np.testing.assert_array_equal(streamed.t["st_count"].cpu().numpy(), ref.to_host()["st_count"])
+    # ... and with a given sample sequence per pair
+    st = ref.to_host()["st_count"]
+    rng = np.random.default_rng(5)
+    samples = np.stack([rng.integers(0, max(int(st[p]), 1), (300, 4)) for p in range(len(frames) - 1)]).astype(np.int32)
+    with_samples = fe.run(packed, samples=samples)
+    streamed = fe.run_streamed(packed, chunk_pairs=3, samples=samples)
+    for p in range(len(frames) - 1):
+        a, c = with_samples.pair(p), streamed.pair(p)
+        for k in a:
+            np.testing.assert_array_equal(a[k], c[k], err_msg=f"{k} pair {p} (streamed, samples)")
 
 
 @pytest.mark.parametrize("nbytes", [61, 32])
