@@ -84,7 +84,11 @@ const char *slamhip_strerror(int code);
  * the stage behind it, sort + filter + triangulation + gather in one launch per stage, the refinement
  * behind the RANSAC replay) or as the launches of a long call (0); identical results; knob 15 =
  * correspondences per one-wavefront block of the consensus count of such calls (0, the default: from
- * the sizes, 32 for one pair; else an even number); identical results; knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
+ * the sizes, 32 for one pair; else an even number); identical results; knob 16 = the first round's
+ * consensus count of a long front-end call as two launches (1, the default: the first 64 hypotheses of
+ * every pair, then the other 192 for the pairs the stopping rule does not end within those 64; later
+ * rounds one workgroup per pair and chunk) or as one launch of one-wavefront workgroups (0); identical
+ * results; knob 0 = 12: the matrix-core matcher with four query groups per wave and one wave
  * per SIMD (64-byte rows only; measured slower).  Process-global; not for use while other threads
  * are inside the library. */
 int slamhip_tune(int knob, int value);

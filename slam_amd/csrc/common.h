@@ -60,6 +60,11 @@ extern int g_small_call_fusion;
 // Correspondences per one-wavefront block of the consensus count of such calls (0 = chosen from
 // the sizes).  Set through slamhip_tune(15, value).
 extern int g_small_call_span;
+// The first round's consensus count of a long call as two launches (1, the default): the first 64
+// hypotheses of every pair, then the other 192 for the pairs that the stopping rule does not end
+// within those 64 (at the reference's published inlier ratio most pairs need fewer than 64).
+// 0 = one launch over all 256.  Same results.  Set through slamhip_tune(16, value).
+extern int g_count_split;
 
 // splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,

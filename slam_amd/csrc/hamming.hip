@@ -1014,6 +1014,7 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 13) slamhip_internal::g_wide_rounds = (value >= 1 && value <= 3) ? value : 2;
   else if (knob == 14) slamhip_internal::g_small_call_fusion = value ? 1 : 0;
   else if (knob == 15) slamhip_internal::g_small_call_span = value > 0 ? (value + 1) & ~1 : 0;
+  else if (knob == 16) slamhip_internal::g_count_split = value ? 1 : 0;
   else if (knob == 10) g_prof_repeat = value >= 1 && value <= 64 ? value : 1;
   else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
   else return SLAMHIP_EINVAL;

@@ -934,6 +934,32 @@ static int wide_rounds() {
   const int w = slamhip_internal::g_wide_rounds;
   return w < 1 ? 1 : (w > kWideRounds ? kWideRounds : w);
 }
+// A counting launch over hypothesis groups 1 .. 3 of a block whose group 0 (hypotheses 0 .. 63 of
+// the block) has been counted by the launch in front: the replay of the stopping rule never
+// reaches hypothesis 64 of block b when the requirement in force there is at most 256 b + 64 --
+// the carried requirement or that of the largest count among the first 64 (the requirement falls
+// as the count grows, and a record is a count above all earlier ones) -- or the cap is.  Those
+// pairs' other hypotheses need no count: whatever their table entries hold is never looked at
+// (replay_round: `reached` is false from there on, and only reached hypotheses set the state).
+struct CountAhead {
+  int block = -1;          // the block's number among the pair's blocks of 256 hypotheses; < 0: no such check
+  int n_iter_max = 0;
+  double p_success = 0.0;
+};
+__device__ __forceinline__ bool stops_within_first_group(const int32_t *__restrict__ row_counts,
+                                                         const int32_t *__restrict__ s, int n,
+                                                         const CountAhead &ahead) {
+  const int at = ahead.block * kHypPerRound + 64;          // the first hypothesis behind the group
+  if (ahead.n_iter_max <= at) return true;
+  const int best0 = s[1], req0 = s[3];
+  int c = __hip_atomic_load(row_counts + (threadIdx.x & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c = max(c, __shfl_xor(c, d, 64));
+  if (req0 <= at) return true;
+  // (the logarithm as the replaying launches take it)
+  return c > best0 && iterations_required(c, n, log(1.0 - ahead.p_success)) <= at;
+}
+
 // One wavefront's share: hypotheses [64 * hyp_group, +64) of table row `row` (a block of
 // pair p's hypotheses) against the pair's correspondences [span0, span0 + span_len).
 template <int MODE>
@@ -1039,6 +1065,62 @@ __device__ __forceinline__ void ransac_count_item(
   if (valid && c) atomicAdd(slot, c);
 }
 
+// The same for hypothesis groups group0 .. 3 of the row over ONE chunk of correspondences (span0,
+// at most kPtsPerChunk of them), one wavefront of the block per group (a third of the blocks to
+// hand out, which is what a launch costs whose blocks mostly leave at once): the launch behind the
+// one that counted group 0 (CountAhead).  Every wavefront stages the chunk (the same values to
+// the same places).  Rectified pairs with the solve launch's fp32 table only.
+__device__ __forceinline__ void ransac_count_rest_item(
+    double *lds, int p, size_t row, int group0, int span0, const int32_t *__restrict__ obase,
+    const int32_t *__restrict__ tm_count, const float *__restrict__ cx, const float *__restrict__ cpl,
+    const float *__restrict__ cpr, const RansacCam &cam, double thresh, const double *__restrict__ rt,
+    int32_t *__restrict__ counts, const int32_t *__restrict__ info, const float *__restrict__ hyp32,
+    const CountAhead &ahead) {
+  if (info[8 * (size_t)p + 7]) return;
+  const int n = tm_count[p];
+  if (span0 >= n) return;
+  if (ahead.block >= 0 && stops_within_first_group(counts + row * kHypPerRound, info + 8 * (size_t)p, n, ahead))
+    return;
+  const int cnt = min(kPtsPerChunk, n - span0);
+  const size_t base = (size_t)obase[p] + span0;
+  const double thr2 = threshold_squared(thresh);
+  float *ldsf = reinterpret_cast<float *>(lds);
+  unsigned umax = 0u, s2max = 0u;
+  const int lane = (int)threadIdx.x & 63;
+  for (int j = lane; 2 * j < cnt; j += 64) {
+    const size_t a = base + 2 * j, b = (2 * j + 1 < cnt) ? a + 1 : a;
+    stage_pair(ldsf + j * kPairStride, cx, cpl, cpr, a, b, umax, s2max);
+  }
+  umax = wave_max_u32(umax);
+  __syncthreads();
+  {
+    const int g = group0 + ((int)threadIdx.x >> 6);
+    const int hyp = g * 64 + lane;
+    int32_t *slot = counts + row * kHypPerRound + hyp;
+    const bool valid = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0;
+    if (!__any(valid)) return;
+    const float *o = hyp32 + row * kHyp32Floats * kHypPerRound + hyp;
+    Hyp32 h32;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { h32.PL[i] = valid ? o[i * kHypPerRound] : 0.0f; h32.PR[i] = 0.0f; }
+    h32.A3xy = valid ? o[24 * kHypPerRound] : 0.0f; h32.Atxy = valid ? o[25 * kHypPerRound] : 0.0f;
+    h32.A3w = valid ? o[26 * kHypPerRound] : 0.0f;  h32.Atw = valid ? o[27 * kHypPerRound] : 0.0f;
+    h32.cR = valid ? o[28 * kHypPerRound] : 0.0f;
+    const Screen32 sc = make_screen(h32, umax, (float)thresh, (float)thr2);
+    if (valid) {
+      auto exact = [&](const float *f) {
+        double Rt[12], PL_[12], PR_[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) Rt[i] = rt[(row * 12 + i) * kHypPerRound + hyp];
+        make_projections(Rt, cam, PL_, PR_);
+        return inlier_exact_staged<true>(f, PL_, PR_, thresh, thr2);
+      };
+      const int c = count_chunk_inliers_screened<true>(ldsf, cnt, h32, sc, thr2, exact);
+      if (c) atomicAdd(slot, c);
+    }
+  }
+}
+
 template <int MODE>
 __device__ __forceinline__ void ransac_count_body(
     const int32_t *__restrict__ obase, const int32_t *__restrict__ tm_count,
@@ -1109,6 +1191,22 @@ __global__ __launch_bounds__(64) void ransac_count_screened_kernel(SLAMHIP_COUNT
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void ransac_count_rectified_kernel(SLAMHIP_COUNT_ARGS) {
   ransac_count_body<2>(SLAMHIP_COUNT_PASS);
+}
+// ... the launch over hypothesis groups group0 .. of a block whose group 0 has been counted
+// (NG wavefronts per block: groups group0 .. group0 + NG - 1; NG = 4 with group0 = 0 and no check
+// ahead is a whole block of hypotheses, one workgroup per pair and chunk)
+template <int NG>
+__global__ __launch_bounds__(64 * NG) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ransac_count_rectified_rest_kernel(SLAMHIP_COUNT_ARGS, int group0, CountAhead ahead) {
+  // grid (pairs rounded up to a multiple of 8, chunks) with n_pairs > 0, else (chunks, 1, pairs);
+  // kHypPerRound / 64 - group0 wavefronts per block; slots == 1, span_points == kPtsPerChunk
+  __shared__ __align__(16) double lds[kPtsPerChunk * kPtStride];
+  const bool by_pair = n_pairs > 0;
+  const int p = by_pair ? blockIdx.x : blockIdx.z;
+  if (by_pair && p >= n_pairs) return;
+  const int span = by_pair ? blockIdx.y : blockIdx.x;
+  ransac_count_rest_item(lds, p, (size_t)p, group0, span * kPtsPerChunk, obase, tm_count, cx, cpl, cpr, cam, thresh,
+                         rt, counts, info, hyp32, ahead);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void ransac_count_rectified_sparse_kernel(SLAMHIP_COUNT_ARGS) {
@@ -1487,10 +1585,33 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
       int span_points = per_span * kPtsPerChunk;
       if (slots > 1 && slamhip_internal::g_small_call_fusion) span_points = min(span_points, small_call_span(np, groups, max_points));
       const int spans = slamhip_ceil_div(max_points > 0 ? max_points : 1, span_points);
-      const dim3 cgrid = by_pair ? dim3((np + 7) / 8 * 8, spans, groups) : dim3(spans, groups, np);
-      hipLaunchKernelGGL(count, cgrid, dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
+      // The first round of a long call as two launches: the first 64 hypotheses of every pair, then
+      // the other 192 where the stopping rule does not end within those 64 (CountAhead).
+      const bool split = r == 0 && slots == 1 && mode == 2 && !sparse && slamhip_internal::g_count_split != 0 &&
+                         prm.n_iter_max > 64 && span_points == kPtsPerChunk;
+      auto cgrid = [&](int gr) { return by_pair ? dim3((np + 7) / 8 * 8, spans, gr) : dim3(spans, gr, np); };
+      // ... and a later round of such a call with one workgroup of four wavefronts per pair and chunk
+      const bool whole = r > 0 && slots == 1 && mode == 2 && !sparse && slamhip_internal::g_count_split != 0 &&
+                         span_points == kPtsPerChunk;
+      if (whole)
+        hipLaunchKernelGGL(ransac_count_rectified_rest_kernel<kHypPerRound / 64>, cgrid(1), dim3(kHypPerRound), 0, st,
+                           obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,
+                           info + 8 * (size_t)g0, span_points, slots, (const float *)hyp32, by_pair ? np : 0, 0,
+                           CountAhead());
+      else
+      hipLaunchKernelGGL(count, cgrid(split ? 1 : groups), dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
                          prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, span_points, slots,
                          (const float *)hyp32, by_pair ? np : 0);
+      if (split) {
+        CountAhead ahead;
+        ahead.block = r;
+        ahead.n_iter_max = prm.n_iter_max;
+        ahead.p_success = prm.p_success;
+        hipLaunchKernelGGL(ransac_count_rectified_rest_kernel<kHypPerRound / 64 - 1>, cgrid(1),
+                           dim3(kHypPerRound - 64), 0, st, obase + g0,
+                           tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0,
+                           span_points, slots, (const float *)hyp32, by_pair ? np : 0, 1, ahead);
+      }
     }
     if (tail) {
       // replay of the last wide round (state and winner pose up to date), then every block left

@@ -221,6 +221,7 @@ int slamhip_internal::g_ransac_mode = 0;
 int slamhip_internal::g_wide_rounds = 2;
 int slamhip_internal::g_small_call_fusion = 1;
 int slamhip_internal::g_small_call_span = 0;
+int slamhip_internal::g_count_split = 1;
 int slamhip_internal::g_xcd_remap = 1;
 
 extern "C" {

@@ -83,6 +83,10 @@ for case in range(cases):
     _lib.lib.slamhip_tune(14, 0)         # a short call through the launches of a long one
     j = snapshot(fe.run(inp), F)
     _lib.lib.slamhip_tune(14, 1)
+    _lib.lib.slamhip_tune(16, 0)         # the first round's consensus count as one launch
+    k16 = snapshot(fe.run(inp), F)
+    _lib.lib.slamhip_tune(16, 1)
+    r10 = same(a, k16)
     r8 = same(a, j)
     r9 = True
     if F <= 12:                          # the same frames pushed one at a time
@@ -97,10 +101,10 @@ for case in range(cases):
                 r9 = (k, rr)
                 break
     r1, r2, r3, r4, r5, r6, r7 = same(a, b), same(a, c), same(a, d), same(a, e), same(a, g), same(a, h), same(a, i)
-    if not all(r is True for r in (r1, r2, r3, r4, r5, r6, r7, r8, r9)):
+    if not all(r is True for r in (r1, r2, r3, r4, r5, r6, r7, r8, r9, r10)):
         bad += 1
         print(f"MISMATCH case {case}: F={F} nfeat={nfeat} rerun={r1} rounds={r2} tail={r3} packed={r4} "
-              f"sort={r5} sparse count={r6} fp64 count={r7} unfused={r8} pushed={r9}", flush=True)
+              f"sort={r5} sparse count={r6} fp64 count={r7} unfused={r8} pushed={r9} one count launch={r10}", flush=True)
     if case % 5 == 0:
         print(f"case {case} ok so far (F={F}, features {nfeat}), mismatches {bad}", flush=True)
 print(f"done: {cases} cases, {bad} mismatches")
