@@ -13,6 +13,10 @@ KF = int(sys.argv[1]) if len(sys.argv) > 1 else 270
 if len(sys.argv) > 2:
     from slam_amd import _lib
     _lib.lib.slamhip_tune(0, int(sys.argv[2]))
+for kv in os.environ.get("SLAMHIP_PROFILE_TUNE", "").split():     # knob=value pairs for slamhip_tune
+    from slam_amd import _lib
+    k, v = kv.split("=")
+    assert _lib.lib.slamhip_tune(int(k), int(v)) == 0
 cam = CameraModel.kitti_like()
 seq = StereoSequence(cam, n_frames=KF * 17, n_features=1500, seed=7, clutter=0.6)
 frames = []
