@@ -1598,6 +1598,11 @@ int run_pair_ransac(const int32_t *obase, const int32_t *tm_count, const float *
                            obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,
                            info + 8 * (size_t)g0, span_points, slots, (const float *)hyp32, by_pair ? np : 0, 0,
                            CountAhead());
+      else if (split)
+        hipLaunchKernelGGL(ransac_count_rectified_rest_kernel<1>, cgrid(1), dim3(64), 0, st,
+                           obase + g0, tm_count + g0, cx, cpl, cpr, prm.cam, prm.thresh, rt, counts,
+                           info + 8 * (size_t)g0, span_points, slots, (const float *)hyp32, by_pair ? np : 0, 0,
+                           CountAhead());
       else
       hipLaunchKernelGGL(count, cgrid(split ? 1 : groups), dim3(64), 0, st, obase + g0, tm_count + g0, cx, cpl, cpr,
                          prm.cam, prm.thresh, rt, counts, info + 8 * (size_t)g0, span_points, slots,
