@@ -25,6 +25,7 @@ from __future__ import annotations
 import numpy as np
 
 from ...frontend.io.camera_model import CameraModel
+from ..tracking.feature_cache import binary_descriptors
 from .loop_verify import PairVerifier
 
 
@@ -74,7 +75,7 @@ class GpuConsensusCheck:
             des = db.features(kf_id)                                       # :157
             links = db.all_frame_links(kf_id)                              # :158
             rows = np.array([[ln.x_left, ln.x_right, ln.y] for ln in links], dtype=np.float64).reshape(-1, 3)
-            des = np.zeros((0, 61), np.uint8) if des is None else np.asarray(des, dtype=np.uint8)
+            des = np.zeros((0, 61), np.uint8) if des is None else binary_descriptors(des, "keyframe descriptors")
             at = self._kf_index[kf_id] = v.add_keyframes([(rows, des)])[0]
         return at
 

@@ -15,6 +15,7 @@ import torch
 
 from ... import _lib, kernels
 from ..._lib import lib, check, VerifyArgs
+from ..tracking.feature_cache import binary_descriptors
 
 
 class VerifyResult(dict):
@@ -122,7 +123,7 @@ class PairVerifier:
                 self._kf = self._empty_store(61)
             return range(n_have, n_have)
         links = np.concatenate([np.asarray(k[0], dtype=np.float64).reshape(-1, 3) for k in keyframes])
-        des = [np.asarray(k[1], dtype=np.uint8) for k in keyframes]
+        des = [binary_descriptors(k[1], "keyframe descriptors") for k in keyframes]
         D = next((d.shape[1] for d in des if d.ndim == 2 and d.shape[1] > 0), 61)
         des = np.concatenate([d.reshape(-1, D) for d in des])
         if self._kf is None:

@@ -34,6 +34,19 @@ Frame = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]
 _NAME = re.compile(r"^(\d+)\.npz$")
 
 
+def binary_descriptors(des, what: str = "descriptors") -> np.ndarray:
+    """The descriptor rows as a contiguous uint8 array.  The batched front-end and the pair
+    verification match under the Hamming norm only: the reference's matcher takes that norm
+    exactly when the descriptors are uint8 (descriptor_matcher.py:23-28) and the L2 norm
+    otherwise, so anything else (SuperPoint's float rows) is refused here instead of being cast
+    -- `DescriptorMatcher.match` matches such rows one pair at a time."""
+    a = np.asarray(des)
+    if a.dtype != np.uint8 and a.size:
+        raise TypeError(f"{what} must be uint8 (binary descriptors, Hamming norm), got {a.dtype}: float descriptors "
+                        f"are matched under the L2 norm by DescriptorMatcher.match, one pair per call")
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
 def frame_path(directory: str, k: int) -> str:
     return os.path.join(directory, f"{k:06d}.npz")
 
@@ -46,8 +59,7 @@ def save_frame(directory: str, k: int, kp_left, kp_right, des_left, des_right) -
         return np.array([k_.pt for k_ in kp], dtype=np.float32).reshape(-1, 2)
 
     kl, kr = pts(kp_left), pts(kp_right)
-    dl = np.ascontiguousarray(des_left, dtype=np.uint8)
-    dr = np.ascontiguousarray(des_right, dtype=np.uint8)
+    dl, dr = binary_descriptors(des_left, "des_left"), binary_descriptors(des_right, "des_right")
     if dl.ndim != 2 or dr.ndim != 2 or dl.shape[1] != dr.shape[1]:
         raise ValueError("descriptors must be (n, D) uint8 with the same D for both images")
     if len(kl) != len(dl) or len(kr) != len(dr):
@@ -122,7 +134,9 @@ class PackedFrames(Sequence):
         d = np.asarray(frames[0][2]).shape[1]
         off_l = np.concatenate([[0], np.cumsum([len(f[0]) for f in frames])]).astype(np.int32)
         off_r = np.concatenate([[0], np.cumsum([len(f[1]) for f in frames])]).astype(np.int32)
-        cat = lambda i, dt, w: np.concatenate([np.asarray(f[i], dtype=dt).reshape(-1, w) for f in frames])
+        def cat(i, dt, w):
+            rows = [binary_descriptors(f[i]) if dt == np.uint8 else np.asarray(f[i], dtype=dt) for f in frames]
+            return np.concatenate([r.reshape(-1, w) for r in rows])
         return cls(cat(0, np.float32, 2), cat(1, np.float32, 2), cat(2, np.uint8, d), cat(3, np.uint8, d),
                    off_l, off_r)
 

@@ -22,7 +22,7 @@ import torch
 from ... import _lib
 from ..._lib import lib, check, FrontendArgs
 from ... import kernels
-from .feature_cache import PackedFrames
+from .feature_cache import PackedFrames, binary_descriptors
 
 Frame = Tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray]
 
@@ -246,8 +246,8 @@ class TrackingFrontend:
             # asynchronous copy
             stage = _staging(i, t_dt, total * w).view(total, w)
             if total:
-                np.concatenate([np.asarray(f[i], dtype=np_dt).reshape(-1, w) for f in frames],
-                               out=stage.numpy())
+                np.concatenate([(binary_descriptors(f[i]) if np_dt == np.uint8 else np.asarray(f[i], dtype=np_dt))
+                                .reshape(-1, w) for f in frames], out=stage.numpy())
             return stage.to(device, non_blocking=True)
 
         _staging_wait()

@@ -23,6 +23,7 @@ import torch
 
 from ..._lib import lib, check, FrontendArgs
 from ... import _lib
+from .feature_cache import binary_descriptors
 from .frontend import FrontendInputs, FrontendResult, TrackingFrontend
 
 # arrays with one entry (of `width` elements) per left feature / per right feature
@@ -176,8 +177,7 @@ class OnlineFrontend:
         has no pose either, fill_database.py:102-137), else the pair (previous, new)."""
         kp_left = np.ascontiguousarray(kp_left, dtype=np.float32).reshape(-1, 2)
         kp_right = np.ascontiguousarray(kp_right, dtype=np.float32).reshape(-1, 2)
-        des_left = np.ascontiguousarray(des_left, dtype=np.uint8)
-        des_right = np.ascontiguousarray(des_right, dtype=np.uint8)
+        des_left, des_right = binary_descriptors(des_left, "des_left"), binary_descriptors(des_right, "des_right")
         if des_left.ndim != 2 or len(des_left) != len(kp_left) or len(des_right) != len(kp_right):
             raise ValueError("keypoints and descriptors differ in length")
         nl, nr, D = len(kp_left), len(kp_right), des_left.shape[1]

@@ -51,9 +51,19 @@ def _workspace(nbytes: int) -> torch.Tensor:
     return ws
 
 
+def _binary(x, what):
+    """Hamming descriptors are uint8 rows; anything else (float rows are matched under the L2
+    norm, descriptor_matcher.py:23-28 of the reference) is refused instead of cast to bytes."""
+    dt = x.dtype if isinstance(x, torch.Tensor) else np.asarray(x).dtype
+    n = x.numel() if isinstance(x, torch.Tensor) else np.asarray(x).size
+    if n and dt not in (torch.uint8, np.dtype(np.uint8)):
+        raise TypeError(f"{what} descriptors must be uint8 for the Hamming matcher, got {dt} (l2_knn2 matches float rows)")
+    return to_device(x, torch.uint8)
+
+
 def _desc_pair(q, t):
-    q = to_device(q, torch.uint8)
-    t = to_device(t, torch.uint8)
+    q = _binary(q, "query")
+    t = _binary(t, "train")
     if q.dim() != 2 or t.dim() != 2:
         raise ValueError("descriptors must be 2-D (rows, bytes)")
     if t.shape[0] > 0 and q.shape[0] > 0 and q.shape[1] != t.shape[1]:

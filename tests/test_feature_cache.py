@@ -44,6 +44,23 @@ def test_keypoint_objects_and_validation(tmp_path):
         fc.save_frame(str(tmp_path), 1, np.zeros((3, 2)), np.zeros((2, 2)), dl, dr[:, :32])  # D differs
 
 
+def test_float_descriptors_are_refused_not_cast(tmp_path):
+    """The reference matches uint8 descriptors under the Hamming norm and anything else under L2
+    (descriptor_matcher.py:23-28); the batched paths are Hamming only and say so instead of
+    casting float rows to bytes."""
+    rng = np.random.default_rng(2)
+    kl, kr, dl, dr = _frame(rng, 4, 3)
+    fl, fr = rng.random((4, 256), dtype=np.float32), rng.random((3, 256), dtype=np.float32)
+    with pytest.raises(TypeError, match="uint8"):
+        fc.save_frame(str(tmp_path), 0, kl, kr, fl, fr)
+    with pytest.raises(TypeError, match="uint8"):
+        fc.PackedFrames.from_frames([(kl, kr, fl, fr)])
+    with pytest.raises(TypeError, match="uint8"):
+        fc.binary_descriptors(dl.astype(np.int32))
+    assert fc.binary_descriptors(dl) is not None and fc.binary_descriptors(np.zeros((0, 61))).dtype == np.uint8
+    fc.PackedFrames.from_frames([(kl, kr, dl, dr)])
+
+
 def test_gaps_and_missing_directory(tmp_path):
     rng = np.random.default_rng(2)
     fc.save_frame(str(tmp_path), 0, *_frame(rng, 2, 2))
