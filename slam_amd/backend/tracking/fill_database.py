@@ -79,7 +79,10 @@ class TrackingPipeline:
         img_l, img_r = self.img_seq[idx]                                        # :102, :141
         kp_l, des_l = self.feature_extractor.detect_and_compute(img_l)          # :104-105, :144-145
         kp_r, des_r = self.feature_extractor.detect_and_compute(img_r)
-        return _pixels(kp_l), _pixels(kp_r), np.ascontiguousarray(des_l), np.ascontiguousarray(des_r)
+        # (an image without features: OpenCV hands back None for its descriptors)
+        width = next((d.shape[1] for d in (des_l, des_r) if d is not None and np.ndim(d) == 2), 61)
+        des_l, des_r = (np.zeros((0, width), np.uint8) if d is None else np.ascontiguousarray(d) for d in (des_l, des_r))
+        return _pixels(kp_l), _pixels(kp_r), des_l, des_r
 
     def build(self, max_frame=2_600, out_path="kitti05_tracks", rel_path="relative_Rts"):
         """As the reference's build() (:85-255): a TrackingDB over frames [0, max_frame), serialised
