@@ -8,7 +8,12 @@ pipeline itself rather than of the three classes it is made of:
 features in both images (fill_database.py:141-145) -- and hands every frame's features to
 the GPU front-end: one frame at a time (`OnlineFrontend.push`, the reference's own loop
 shape with the previous frame carried over, :234-240) or, with `batched=True`, all frames in
-one call once they are extracted.  Both give the same results.  The per-frame records then
+one call once they are extracted.  Both give the same results.  Those two paths are the
+Hamming ones; float descriptors (the reference's `--feature-type superpoint` with the "bf"
+matcher, which BFMatcher pairs under the L2 norm, descriptor_matcher.py:23-28) take the
+reference's own loop instead, one call per stage and frame through the three classes
+(`_build_stagewise`): every stage still runs on the device, without the fused launches.
+The per-frame records then
 go through the reference's unchanged `TrackingDB.add_frame` in frame order (:133, :231), the
 DB is serialised and the relative poses are pickled to the file `relative_Rts` (:249-255).
 
@@ -21,6 +26,7 @@ is importable, or takes any objects with the same two methods (`img_seq[i] -> (l
 """
 from __future__ import annotations
 
+import itertools
 from typing import Callable, Optional
 
 import numpy as np
@@ -28,6 +34,10 @@ import numpy as np
 from . import db_adapter
 from .frontend import TrackingFrontend
 from .online import OnlineFrontend, OnlineRecords
+from ...frontend.geometry.pnp import PnP, SOLVEPNP_ITERATIVE
+from ...frontend.geometry.triangulation import Triangulation
+from ...frontend.vision.descriptor_matcher import DescriptorMatcher
+from ...types import MatchList
 
 
 def _pixels(kps) -> np.ndarray:
@@ -84,6 +94,47 @@ class TrackingPipeline:
         des_l, des_r = (np.zeros((0, width), np.uint8) if d is None else np.ascontiguousarray(d) for d in (des_l, des_r))
         return _pixels(kp_l), _pixels(kp_r), des_l, des_r
 
+    def _build_stagewise(self, frames) -> OnlineRecords:
+        """The reference's loop (:101-240) over the three classes, for descriptors the fused
+        front-end does not take (anything but uint8): stereo match -> row / disparity filter
+        -> triangulate per frame, then match the previous frame's stereo inliers to this
+        frame's, RANSAC over the correspondences and refine on the inliers.  `frames`
+        yields (kp_left, kp_right, des_left, des_right); the records have the layout of the
+        fused paths'.  The sampler is a NumPy generator seeded with `seed`."""
+        P = self._params
+        stereo = DescriptorMatcher(cross_check=P["stereo_cross_check"])           # :55-57
+        temporal = DescriptorMatcher(cross_check=P["frame_cross_check"])          # :58-60
+        triang = Triangulation(self.cam, P["disparity_min"], P["pixel_thresh"])   # :62-63
+        pnp = PnP(self.cam, P["pixel_thresh"])                                    # :64
+        rng = np.random.default_rng(P["seed"])
+        out = OnlineRecords(P["frame_cross_check"])
+        prev = None
+        for f, (kp_l, kp_r, des_l, des_r) in enumerate(frames):
+            lr = stereo.match(des_l, des_r)                                       # :114, :155
+            lr = triang.create_inlier_outlier_matches(lr, kp_l, kp_r)[0]          # :116-118, :158-160
+            if len(lr) == 0:
+                lr = MatchList([], [], [])
+            q, t = lr.query_idx, lr.train_idx
+            cur = {"left_idx": q, "right_idx": t, "dist": lr.distance,
+                   "xyz": triang.triangulate_opencv(kp_l, kp_r, lr).reshape(-1, 3),   # :121, :163
+                   "pix_left": kp_l[q], "pix_right": kp_r[t],
+                   "inlier_des_left": np.ascontiguousarray(des_l[q])}             # create_links, :124-131
+            out._frames.append(cur)
+            if prev is not None:
+                m01 = temporal.match(prev["inlier_des_left"], cur["inlier_des_left"])   # :185
+                X = prev["xyz"][m01.query_idx]                                    # :189-190
+                pix_l, pix_r = cur["pix_left"][m01.train_idx], cur["pix_right"][m01.train_idx]   # :195-197
+                mask = pnp.ransac_pnp_pair1(X, pix_l, pix_r, rng=rng) if len(X) >= 4 else None   # :200-202
+                if mask is None:
+                    # the reference indexes with the missing mask and fails two lines later
+                    raise RuntimeError(f"frames {f - 1} -> {f}: no pose hypothesis with an inlier "
+                                       f"among {len(X)} correspondences")
+                Rt = pnp.solve_pnp(X[mask], pix_l[mask], SOLVEPNP_ITERATIVE)      # :204-207
+                out._pairs.append({"query_idx": m01.query_idx, "train_idx": m01.train_idx,
+                                   "dist": m01.distance, "mask": mask, "Rt": np.asarray(Rt, dtype=np.float64)})
+            prev = cur
+        return out
+
     def build(self, max_frame=2_600, out_path="kitti05_tracks", rel_path="relative_Rts"):
         """As the reference's build() (:85-255): a TrackingDB over frames [0, max_frame), serialised
         to `out_path`, the relative poses cached and pickled to `rel_path`.  Returns the DB."""
@@ -98,14 +149,17 @@ class TrackingPipeline:
                 raise ImportError("no db_factory / link_factory given and the reference's TrackingDB "
                                   "(slam.backend.tracking.database) cannot be imported") from e
             db_factory, link_factory = db_factory or TrackingDB, link_factory or Link
-        if self.batched:
-            frames = [self._frame(idx) for idx in range(total)]
-            result = TrackingFrontend(self.cam, **self._params).run(frames)
+        first = self._frame(0)
+        rest = (self._frame(idx) for idx in range(1, total))                    # :140
+        if first[2].dtype != np.uint8:
+            result = self._build_stagewise(itertools.chain([first], rest))
+        elif self.batched:
+            result = TrackingFrontend(self.cam, **self._params).run([first, *rest])
         else:
             online = OnlineFrontend(self.cam, **self._params)
             result = OnlineRecords(self._params["frame_cross_check"])
-            for idx in range(total):                                            # :140
-                pair = online.push(*self._frame(idx))
+            for frame in itertools.chain([first], rest):
+                pair = online.push(*frame)
                 if pair is not None:
                     result.add(pair)
         db = db_adapter.replay_into_db(db_factory(), result, link_factory=link_factory, n_frames=total)

@@ -131,3 +131,53 @@ def test_tracking_pipeline_with_the_references_constructor_and_build(golden, bat
     for key in a:
         np.testing.assert_array_equal(a[key], b[key], err_msg=key)
     assert len(pipe.matches_per_frame) == F - 1 and all(i <= m for i, m in zip(pipe.inliers_per_frame, pipe.matches_per_frame))
+
+
+def test_tracking_pipeline_with_float_descriptors_runs_the_three_classes(golden, tmp_path):
+    """Float descriptors (the reference's SuperPoint features with the "bf" matcher) are paired
+    under the L2 norm (descriptor_matcher.py:23-28), which the fused Hamming front-end does not
+    do: build() then walks the reference's loop over DescriptorMatcher / Triangulation / PnP.
+    Here the float rows are the golden binary rows unpacked to one 0.0 / 1.0 per bit, so an L2
+    distance is the square root of the Hamming distance and every match, stereo inlier, 3-D
+    point and link must equal the Hamming run's; only the sampler differs (NumPy's, as the
+    reference's), so masks may differ in borderline rows and poses agree to the tolerance of
+    the comparison with the reference's own poses."""
+    from oracle.tracking_db_oracle import TrackDBOracle
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking import db_adapter
+    from slam_amd.backend.tracking.fill_database import TrackingPipeline
+    from slam_amd.backend.tracking.frontend import TrackingFrontend
+    g = golden("ref_build_flow.npz")
+    F = int(g["n_frames"])
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+
+    class Images:
+        def __len__(self):
+            return F
+
+        def __getitem__(self, k):
+            return ("left", k), ("right", k)
+
+    class FloatExtractor:
+        def detect_and_compute(self, img):
+            side, k = img
+            return g[f"kp_{side}_{k}"], np.unpackbits(g[f"des_{side}_{k}"], axis=1).astype(np.float32)
+
+    for cross in (False, True):
+        pipe = TrackingPipeline(cam, Images(), 2e-3, 1.2, 4.0, False, cross, "superpoint", "bf", True,
+                                feature_extractor=FloatExtractor(), db_factory=TrackDBOracle,
+                                link_factory=db_adapter.Link, seed=3)
+        db = pipe.build(max_frame=F, out_path=None, rel_path=str(tmp_path / "relative_Rts"))
+        frames = [(g[f"kp_left_{k}"], g[f"kp_right_{k}"], g[f"des_left_{k}"], g[f"des_right_{k}"]) for k in range(F)]
+        want = TrackingFrontend(cam, disparity_min=1.2, pixel_thresh=4.0, seed=3, frame_cross_check=cross).run(frames)
+        for k in range(F):
+            links = np.asarray(db.all_frame_links(k), np.float64).reshape(-1, 3)
+            np.testing.assert_array_equal(links, g[f"links_{k}"], err_msg=f"frame {k}")
+        got_Rts = pipe.get_relative_Rts()
+        assert got_Rts.shape == (F - 1, 3, 4)
+        assert np.abs(got_Rts - want.relative_Rts()).max() < 0.05
+        assert np.abs(got_Rts - g["relative_Rts"]).max() < 0.05
+        assert len(pipe.matches_per_frame) == F - 1
+        for p in range(F - 1):
+            assert pipe.matches_per_frame[p] == len(want.pair(p)["mask"])
+            assert abs(pipe.inliers_per_frame[p] - int(want.pair(p)["mask"].sum())) <= 0.05 * len(want.pair(p)["mask"])
