@@ -15,7 +15,7 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 // per iteration: 2 matrix instructions (two accumulators), each followed by NFILL vector
 // instructions and NLDS ds_read_b128
 template <int NFILL, int NLDS, bool MFMA>
-__global__ __launch_bounds__(256) void mix(int iters, float *sink, unsigned *cycles) {
+__global__ __launch_bounds__(256) void mix(int iters, float *sink, unsigned *cycles, int operands) {
   __shared__ v4i lds[1024];
   lds[threadIdx.x] = v4i{(int)threadIdx.x, 1, 2, 3};
   __syncthreads();
@@ -23,6 +23,10 @@ __global__ __launch_bounds__(256) void mix(int iters, float *sink, unsigned *cyc
   for (int i = 0; i < 16; ++i) { acc0[i] = (float)(threadIdx.x + i); acc1[i] = (float)(threadIdx.x * 3 + i); }
   v4i fa = {(int)(0x2A2A2A2A ^ (threadIdx.x * 0x08080808u)), 0x22AA22AA, 0x2A2AA2A2, 0x22222222};
   v4i fb = {0x2AA22AA2, (int)(0xA2A2A2A2 ^ (threadIdx.x * 0x80808080u)), 0x2222AAAA, 0x2A2A2A2A};
+  // operands: 0 = +-1 in every nibble (what the matcher feeds), 1 = all zero, 2 = 0 / +1 on one
+  // side and 0 / -1 on the other (half of the products are zero)
+  if (operands == 1) { fa = v4i{0, 0, 0, 0}; fb = v4i{0, 0, 0, 0}; }
+  if (operands == 2) { for (int j = 0; j < 4; ++j) { fa[j] &= 0x22222222; fb[j] &= (int)0xAAAAAAAA; } }
   int sc = 127;
   float x[8];
   for (int j = 0; j < 8; ++j) x[j] = (float)(threadIdx.x + j);
@@ -115,14 +119,16 @@ void run16(int blocks, int iters, float *sink, unsigned *cyc) {
          "equivalent\n", NFILL, wps, ms, ms * 1e6 / (2.0 * iters * wps), 2.0 * ms * 1e6 / (2.0 * iters * wps));
 }
 
+static int g_operands = 0;
+
 template <int NFILL, int NLDS, bool MFMA>
 void run(int blocks, int iters, float *sink, unsigned *cyc) {
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  hipLaunchKernelGGL((mix<NFILL, NLDS, MFMA>), dim3(blocks), dim3(256), 0, 0, iters, sink, cyc);
+  hipLaunchKernelGGL((mix<NFILL, NLDS, MFMA>), dim3(blocks), dim3(256), 0, 0, iters, sink, cyc, g_operands);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL((mix<NFILL, NLDS, MFMA>), dim3(blocks), dim3(256), 0, 0, iters, sink, cyc);
+  hipLaunchKernelGGL((mix<NFILL, NLDS, MFMA>), dim3(blocks), dim3(256), 0, 0, iters, sink, cyc, g_operands);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
@@ -135,10 +141,21 @@ void run(int blocks, int iters, float *sink, unsigned *cyc) {
          (double)c / (2.0 * iters), (double)c / (2.0 * iters * wps), c / (ms * 1e6));
 }
 
-int main() {
+int main(int argc, char **argv) {
   float *sink; unsigned *cyc;
   CK(hipMalloc(&sink, 64)); CK(hipMalloc(&cyc, 64));
   const int iters = 20000;
+  if (argc > 1) {   // operand study: the bare instruction and the matcher's mix, per operand kind
+    for (int kind = 0; kind < 3; ++kind) {
+      g_operands = kind;
+      printf("operands %d (0: +-1 everywhere, 1: all zero, 2: half of the products zero)\n", kind);
+      for (int rep = 0; rep < atoi(argv[1]); ++rep) {
+        run<0, 0, true>(512, 4 * iters, sink, cyc);
+        run<4, 1, true>(512, 4 * iters, sink, cyc);
+      }
+    }
+    return 0;
+  }
   for (int blocks : {256, 512}) {
     run<0, 0, true>(blocks, iters, sink, cyc);
     run<2, 0, true>(blocks, iters, sink, cyc);
