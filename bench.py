@@ -66,6 +66,10 @@ OPS_PER_COMPARE = 2 * ((DESC_BYTES + 3) // 4)
 # Matrix-core matcher: one multiply-add per descriptor bit; the instruction stream pads rows to
 # 8 / 16 / 32 dwords.  Peak: MI355X block-scaled FP4 MFMA, dense (no sparsity).
 MFMA_PEAK_FLOPS = 10.0e15
+# What the instruction sustains on this chip when nothing stands beside it and its operands are +-1 in every
+# element, as descriptor bits are (profiles/r3/mfma_operands_clock.log: one issue per 33.5 cycles and SIMD at the
+# 2.17-2.19 GHz the chip holds under it once warm; the clock follows the operand bits, all-zero operands run at 2.37).
+MFMA_SUSTAINED_FLOPS = 2 * 32 * 32 * 64 * N_SIMD / (33.5 / 2.19e9)
 # HBM-side bytes per matrix-core top-2 launch, same recipe (profiles/r3/pmc_matcher8k.txt, final build:
 # FETCH_SIZE 2294 KB x2 + WRITE_SIZE 1024 KB; profiles/r2/pmc_matcher8k_mfma.txt had 2276).  The reads are the
 # rows arriving in eight L2s, one per XCD: each holds two query blocks' rows (62 KB) and every train row (500 KB).
@@ -95,6 +99,10 @@ def matcher_roofline(mfma, compares, kernel_s, n_launch, desc_bytes=DESC_BYTES):
                 "peak_source": "MI355X_MICROARCH.md: FP4 block-scaled MFMA ~10 PF dense "
                                "(v_mfma_scale_f32_32x32x64_f8f6f4, 32 cycles per SIMD at 2.4 GHz)",
                 "achieved_issued": issued / 1e12, "frac_issued": issued / MFMA_PEAK_FLOPS,
+                "sustained_instruction_peak": MFMA_SUSTAINED_FLOPS / 1e12,
+                "frac_of_sustained_instruction_peak": achieved / MFMA_SUSTAINED_FLOPS,
+                "sustained_source": "profiles/r3/mfma_operands_clock.log (tools/mfma_mix_probe 3): the bare instruction "
+                                    "with +-1 operands, 33.5 cycles per issue and SIMD at 2.19 GHz",
                 "issued_note": f"{flop_per_compare(desc_bytes, True)} flop per compare pass through "
                                "the matrix cores: rows are zero padded to 64 bytes",
                 "kernel_us": kernel_s * 1e6, "launches_timed": n_launch, **hbm,
