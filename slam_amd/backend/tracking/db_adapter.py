@@ -64,7 +64,8 @@ def replay_into_db(db, result, link_factory: Callable = Link, n_frames: Optional
     pickled for the reference's loader.  `frame_cross_check` (default: what `result`
     records, else False) selects the reference's two hand-over shapes: without it the
     compact matches in sorted order, one per previous row; with it the densified list
-    (`dense_matches`), as add_frame requires one entry per previous row."""
+    (`dense_matches`), as add_frame requires one entry per previous row (also used when a frame
+    without stereo inliers leaves the previous rows without matches)."""
     if n_frames is None:
         n_frames = result.n_frames if hasattr(result, "n_frames") else result.inputs.n_frames
     if frame_cross_check is None:
@@ -78,7 +79,9 @@ def replay_into_db(db, result, link_factory: Callable = Link, n_frames: Optional
             db.add_frame(links, des, None)
         else:
             pr = result.pair(f - 1)
-            if frame_cross_check:
+            if frame_cross_check or len(pr["query_idx"]) != n_prev:
+                # (without cross-check every previous row has a match unless this frame kept no
+                # stereo inlier at all; add_frame wants one entry per previous row either way, :332)
                 matches, mask = dense_matches(pr, n_prev)
             else:
                 matches = MatchList(pr["query_idx"], pr["train_idx"], pr["dist"].astype(np.float32))

@@ -126,10 +126,12 @@ class TrackingPipeline:
                 pix_l, pix_r = cur["pix_left"][m01.train_idx], cur["pix_right"][m01.train_idx]   # :195-197
                 mask = pnp.ransac_pnp_pair1(X, pix_l, pix_r, rng=rng) if len(X) >= 4 else None   # :200-202
                 if mask is None:
-                    # the reference indexes with the missing mask and fails two lines later
-                    raise RuntimeError(f"frames {f - 1} -> {f}: no pose hypothesis with an inlier "
-                                       f"among {len(X)} correspondences")
-                Rt = pnp.solve_pnp(X[mask], pix_l[mask], SOLVEPNP_ITERATIVE)      # :204-207
+                    # fewer correspondences than a sample, or no hypothesis with an inlier: the reference
+                    # fails here (it indexes with the missing mask); as in the fused paths the pair is
+                    # recorded without inliers and with the identity as its pose
+                    mask, Rt = np.zeros(len(X), dtype=bool), np.hstack([np.eye(3), np.zeros((3, 1))])
+                else:
+                    Rt = pnp.solve_pnp(X[mask], pix_l[mask], SOLVEPNP_ITERATIVE)  # :204-207
                 out._pairs.append({"query_idx": m01.query_idx, "train_idx": m01.train_idx,
                                    "dist": m01.distance, "mask": mask, "Rt": np.asarray(Rt, dtype=np.float64)})
             prev = cur

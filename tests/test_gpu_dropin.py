@@ -181,3 +181,59 @@ def test_tracking_pipeline_with_float_descriptors_runs_the_three_classes(golden,
         for p in range(F - 1):
             assert pipe.matches_per_frame[p] == len(want.pair(p)["mask"])
             assert abs(pipe.inliers_per_frame[p] - int(want.pair(p)["mask"].sum())) <= 0.05 * len(want.pair(p)["mask"])
+
+    class NoRightFeaturesInFrame1(FloatExtractor):       # frame 1 keeps no stereo inlier: its two pairs have no match
+        def detect_and_compute(self, img):
+            kp, des = super().detect_and_compute(img)
+            return (kp[:0], des[:0]) if img == ("right", 1) else (kp, des)
+
+    pipe = TrackingPipeline(cam, Images(), 2e-3, 1.2, 4.0, False, False, "superpoint", "bf", True,
+                            feature_extractor=NoRightFeaturesInFrame1(), db_factory=TrackDBOracle,
+                            link_factory=db_adapter.Link, seed=3)
+    db = pipe.build(max_frame=F, out_path=None, rel_path=None)
+    assert len(db.all_frame_links(1)) == 0 and pipe.matches_per_frame[:2] == [0, 0]
+    identity = np.hstack([np.eye(3), np.zeros((3, 1))])
+    np.testing.assert_array_equal(pipe.get_relative_Rts()[:2], [identity, identity])
+    if F > 3:
+        assert np.abs(pipe.get_relative_Rts()[2] - g["relative_Rts"][2]).max() < 0.05
+
+
+@pytest.mark.parametrize("batched", [False, True])
+def test_tracking_pipeline_survives_a_frame_without_stereo_inliers(golden, batched):
+    """A frame whose right image gave no features keeps no stereo inlier, so the frames before
+    and after it have nothing to match against.  The reference's loop fails there
+    (fill_database.py:200-207 indexes with a missing mask, database.py:332 wants one match per
+    previous row); here the two pairs are recorded without matches and with the identity as
+    their pose, add_frame gets the densified hand-over, and the sequence goes on."""
+    from oracle.tracking_db_oracle import TrackDBOracle
+    from slam_amd import CameraModel
+    from slam_amd.backend.tracking import db_adapter
+    from slam_amd.backend.tracking.fill_database import TrackingPipeline
+    g = golden("ref_build_flow.npz")
+    F = int(g["n_frames"])
+    cam = CameraModel.from_projections(g["P0"], g["P1"])
+
+    class Images:
+        def __len__(self):
+            return F
+
+        def __getitem__(self, k):
+            return ("left", k), ("right", k)
+
+    class Extractor:
+        def detect_and_compute(self, img):
+            side, k = img
+            if img == ("right", 1):
+                return [], None                       # what OpenCV returns for an image without features
+            return g[f"kp_{side}_{k}"], g[f"des_{side}_{k}"]
+
+    pipe = TrackingPipeline(cam, Images(), 2e-3, 1.2, 4.0, False, False, "akaze", "bf", True,
+                            feature_extractor=Extractor(), db_factory=TrackDBOracle,
+                            link_factory=db_adapter.Link, batched=batched, seed=3)
+    db = pipe.build(max_frame=F, out_path=None, rel_path=None)
+    assert len(db.all_frame_links(1)) == 0 and pipe.matches_per_frame[:2] == [0, 0]
+    np.testing.assert_array_equal(np.asarray(db.all_frame_links(0), np.float64).reshape(-1, 3), g["links_0"])
+    identity = np.hstack([np.eye(3), np.zeros((3, 1))])
+    np.testing.assert_array_equal(pipe.get_relative_Rts()[:2], [identity, identity])
+    if F > 3:
+        assert np.abs(pipe.get_relative_Rts()[2] - g["relative_Rts"][2]).max() < 0.05
