@@ -66,6 +66,13 @@ extern int g_small_call_span;
 // 0 = one launch over all 256.  Same results.  Set through slamhip_tune(16, value).
 extern int g_count_split;
 
+// Duration probe of the matrix-core top-2 kernel by the dispatch's own timestamps: while both are
+// set, the next launch of that kernel goes out through hipExtLaunchKernelGGL with these two events,
+// which then hold the start and the end of the kernel itself (what a kernel trace reports), with
+// no event record of its own on the stream.  Set and cleared by the matcher's host code around
+// the launch (slamhip_tune(10, 0) selects this probe).
+extern hipEvent_t g_dispatch_start, g_dispatch_stop;
+
 // splits > 0 pins the number of train splits (see knn2_plan_splits); 0 = chosen from the sizes.
 size_t knn2_workspace_bytes(int nq_total, int nt_total, int n_pairs, int max_nq, int max_nt,
                             int desc_bytes, long long n_out = -1, bool prepacked = false,

@@ -669,7 +669,7 @@ bool default_mfma() {
 int g_force_splits = 0;
 int g_mfma_target_blocks = 512;    // matrix-core kernel: blocks a launch aims at (knob 6)
 int g_mfma_rows_per_split = 4096;  // and train rows per block it does not exceed when blocks abound (knob 7)
-int g_prof_repeat = 1;     // knob 10: launches of the top-2 kernel per probed call (see run_knn2)
+int g_prof_repeat = 1;     // knob 10: launches of the top-2 kernel per probed call; 0 = one launch timed by its own dispatch (see run_knn2)
 int g_raw_rows = 1;        // knob 9: matrix-core kernel reads unpacked rows itself (0 = packing launch first)
 int g_fold_in_kernel = 2;  // knob 8: 0 = always the separate merge launch, 1 = never, 2 = by size
 int g_force_threads = 0;   // 0 auto, else 256 or 128 threads per matcher block
@@ -882,9 +882,17 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 
   const dim3 grid(p.qblocks, p.splits, n_pairs);
   std::pair<hipEvent_t, hipEvent_t> *ev = nullptr;
+  // knob 10 = 0: the two events are handed to the launch itself and hold the dispatch's own start
+  // and end (matrix-core kernel only; the popcount family keeps the records around the launch)
+  const bool by_dispatch = g_prof_repeat == 0 && p.mfma;
   if (g_prof.enabled && g_prof.used < g_prof.pool.size()) {
     ev = &g_prof.pool[g_prof.used++];
-    (void)hipEventRecord(ev->first, st);
+    if (by_dispatch) {
+      slamhip_internal::g_dispatch_start = ev->first;
+      slamhip_internal::g_dispatch_stop = ev->second;
+    } else {
+      (void)hipEventRecord(ev->first, st);
+    }
   }
   const int nqs = d_q_off ? 0 : nq_total, nts = d_q_off ? 0 : nt_total;
 #define SLAMHIP_DISPATCH(WW, QQ, LL)                                                        \
@@ -926,7 +934,8 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
 #undef SLAMHIP_DISPATCH
 #undef SLAMHIP_DISPATCH_HALF
 #undef SLAMHIP_DISPATCH_BEST
-  if (ev) (void)hipEventRecord(ev->second, st);
+  if (ev && by_dispatch) slamhip_internal::g_dispatch_start = slamhip_internal::g_dispatch_stop = nullptr;
+  else if (ev) (void)hipEventRecord(ev->second, st);
   SLAMHIP_CHECK_LAUNCH();
 
   if (p.fold_in_kernel) {
@@ -1015,7 +1024,7 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 14) slamhip_internal::g_small_call_fusion = value ? 1 : 0;
   else if (knob == 15) slamhip_internal::g_small_call_span = value > 0 ? (value + 1) & ~1 : 0;
   else if (knob == 16) slamhip_internal::g_count_split = value ? 1 : 0;
-  else if (knob == 10) g_prof_repeat = value >= 1 && value <= 64 ? value : 1;
+  else if (knob == 10) g_prof_repeat = value >= 0 && value <= 64 ? value : 1;
   else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;

@@ -41,6 +41,7 @@
 // Both operands are fetched the same way (lane l: row l & 31, 16-byte chunk l >> 5 of the
 // k-step), so whatever order the instruction gives the 64 k positions is the same for A and B.
 #include "common.h"
+#include <hip/hip_ext.h>
 
 #ifndef SLAMHIP_ABLATE
 #define SLAMHIP_ABLATE 0
@@ -654,6 +655,18 @@ void launch(dim3 grid, hipStream_t st, const uint32_t *qp, const uint32_t *tp, c
   if (grid.z >= 64 && grid.x * grid.y > 1 && arrivals == nullptr && slamhip_internal::g_xcd_remap != 0) {
     xq = (int)grid.x; xs = (int)grid.y; xp = (int)grid.z;
     grid = dim3(grid.x * grid.y * ((grid.z + 7) / 8 * 8), 1, 1);
+  }
+  hipEvent_t t0 = slamhip_internal::g_dispatch_start, t1 = slamhip_internal::g_dispatch_stop;
+  if (t0 != nullptr && t1 != nullptr) {   // duration probe: the dispatch's own start and end
+    if (raw != nullptr)
+      hipExtLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, true>), grid, dim3(64 * NW), 0, st, t0, t1, 0, qp, tp,
+                            q_off, q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio,
+                            keep, raw->row_stride, raw->desc_bytes, xq, xs, xp);
+    else
+      hipExtLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, false>), grid, dim3(64 * NW), 0, st, t0, t1, 0, qp, tp,
+                            q_off, q_cnt, t_off, t_cnt, out_off, nq, nt, nq_total, part, idx2, dist2, arrivals, ratio,
+                            keep, 0, 0, xq, xs, xp);
+    return;
   }
   if (raw != nullptr)
     hipLaunchKernelGGL((hamming_mfma_kernel<W, G, BEST, NW, true>), grid, dim3(64 * NW), 0, st, qp, tp, q_off,

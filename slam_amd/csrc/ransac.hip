@@ -223,6 +223,7 @@ int slamhip_internal::g_small_call_fusion = 1;
 int slamhip_internal::g_small_call_span = 0;
 int slamhip_internal::g_count_split = 1;
 int slamhip_internal::g_xcd_remap = 1;
+hipEvent_t slamhip_internal::g_dispatch_start = nullptr, slamhip_internal::g_dispatch_stop = nullptr;
 
 extern "C" {
 
