@@ -866,6 +866,26 @@ def main():
         except Exception as e:  # noqa: BLE001  (the events recorded around the launch remain)
             print(f"bench: dispatch-event probe failed ({e}); using the recorded events", file=sys.stderr)
             check(_lib.lib.slamhip_tune(10, 1), "slamhip_tune")
+    # Differential figure, no events at all: the same K steps timed by the host clock with the top-2
+    # kernel launched twice in every step (identical, idempotent launches), minus the K steps with one
+    # launch: what one more launch of the kernel costs inside the step, its launch gap included.
+    def timed_steps(launches_per_step):
+        check(_lib.lib.slamhip_tune(10, -launches_per_step if launches_per_step > 1 else 1), "slamhip_tune")
+        for _ in range(args.warmup):
+            step()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        check(_lib.lib.slamhip_tune(10, 1), "slamhip_tune")
+        return dt / args.steps
+    kernel_s_differential = None
+    if mfma:
+        one = min(timed_steps(1) for _ in range(3))
+        two = min(timed_steps(2) for _ in range(3))
+        kernel_s_differential = two - one
     # (under rocprofv3 the profiler owns the dispatch signals and these events read ~26 us: the
     # events recorded around the launch are then the headline again, and the line says so)
     by_dispatch = bool(mfma and kernel_s_dispatch is not None and 0.0 < kernel_s_dispatch <= kernel_s_single)
@@ -913,6 +933,10 @@ def main():
                              frac_events_around_one_launch=matcher_roofline(mfma, compares, kernel_s_single, n_launch)["frac"],
                              events_around_one_launch_note="two event records on the stream around the launch; their own "
                                                            "cost (2-3 us) is inside the interval",
+                             kernel_us_differential=None if kernel_s_differential is None else kernel_s_differential * 1e6,
+                             differential_method="host-clock time of the steps with the kernel launched twice in each, "
+                                                 "minus the steps as they are (best of three each): one more launch "
+                                                 "inside the step, launch gap included, no events",
                              kernel_us_back_to_back=kernel_s * 1e6,
                              frac_back_to_back=matcher_roofline(mfma, compares, kernel_s, n_launch)["frac"],
                              back_to_back_method=f"{PROBE_REPEAT} identical launches between the two events"),

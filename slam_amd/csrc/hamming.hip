@@ -907,7 +907,10 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
   // Under the duration probe the top-2 kernel may be launched several times back to back between
   // the two events (knob 10; the launches are identical and idempotent), so that the events'
   // own cost is spread over them.
-  const int launches = (ev != nullptr && !p.fold_in_kernel && g_prof_repeat > 1) ? g_prof_repeat : 1;
+  // (knob 10 < 0: that many launches in every call, no events: for timing the step with one more
+  // launch of the kernel in it)
+  const int launches = p.fold_in_kernel ? 1
+                       : (g_prof_repeat < 0 ? -g_prof_repeat : (ev != nullptr && g_prof_repeat > 1 ? g_prof_repeat : 1));
   for (int rep = 0; rep < launches; ++rep) {
   if (p.mfma) {
     slamhip_internal::launch_hamming_mfma(p.W, p.G, p.NW, best_only, grid, st, qp, tp, d_q_off, d_q_cnt, d_t_off,
@@ -1024,7 +1027,7 @@ int slamhip_tune(int knob, int value) {
   else if (knob == 14) slamhip_internal::g_small_call_fusion = value ? 1 : 0;
   else if (knob == 15) slamhip_internal::g_small_call_span = value > 0 ? (value + 1) & ~1 : 0;
   else if (knob == 16) slamhip_internal::g_count_split = value ? 1 : 0;
-  else if (knob == 10) g_prof_repeat = value >= 0 && value <= 64 ? value : 1;
+  else if (knob == 10) g_prof_repeat = value >= -8 && value <= 64 ? value : 1;
   else if (knob == 8) g_fold_in_kernel = (value >= 0 && value <= 2) ? value : 2;
   else return SLAMHIP_EINVAL;
   return SLAMHIP_OK;
