@@ -76,8 +76,9 @@ const char *slamhip_strerror(int code);
  * identical launches back to back between the probe's two events, which spreads the events' own
  * cost; slamhip_profile_end then reports the time of all of them; 0: one launch, and the probe's
  * two events are handed to that launch itself (hipExtLaunchKernelGGL), so that they hold the start and
- * the end of the dispatch - the duration a kernel trace reports - with no event record on the stream;
- * matrix-core kernel only; -2 .. -8: that many launches of the kernel in every call, probe or not, so that a
+ * the end of the dispatch - the duration a kernel trace reports - with no event record on the stream
+ * (the merge launch behind it is then given events of its own as well, never read: a dispatch with a
+ * profiling signal among dispatches without one reads 1-2 us longer); matrix-core kernel only; -2 .. -8: that many launches of the kernel in every call, probe or not, so that a
  * caller can time its step with one more launch in it), knob 11 = batched launches
  * of the matrix-core matcher (64 pairs or more) deal their blocks to the chip's eight XCDs pair
  * by pair, so that a pair's rows come into one L2 (1, the default), or use the plain grid (0);

@@ -19,6 +19,7 @@
 // distances, for the best and for the second best
 // (call site: frontend/vision/descriptor_matcher.py:33 of the reference).
 #include "common.h"
+#include <hip/hip_ext.h>
 #include "sort_device.h"
 #include <atomic>
 #include <cstdlib>
@@ -947,7 +948,14 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     unfolded->part = part;     // the caller's next kernel folds the splits
     unfolded->splits = p.splits;
   } else if (p.splits > 1) {
-    if (p.splits >= 16)
+    if (p.splits >= 16 && ev != nullptr && by_dispatch) {
+      // under the dispatch probe the merge launch carries events of its own too (never read): every
+      // dispatch of the probed steps then has a profiling signal, as under a kernel trace
+      static hipEvent_t m0 = nullptr, m1 = nullptr;
+      if (m0 == nullptr && (hipEventCreate(&m0) != hipSuccess || hipEventCreate(&m1) != hipSuccess)) return SLAMHIP_ELAUNCH;
+      hipExtLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
+                            0, st, m0, m1, 0, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
+    } else if (p.splits >= 16)
       hipLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
                          0, st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
     else
