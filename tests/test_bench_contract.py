@@ -53,3 +53,20 @@ def test_cpu_baseline_fields(line):
     fe = line.get("frontend")
     if fe:
         assert fe["metric"] == "frontend_frames_per_sec" and "roofline" in fe and "cpu_baseline" in fe
+
+
+def test_headline_duration_is_one_of_the_measured_ones(line):
+    """`roofline.kernel_us` is the duration the launch-filled events report (or, where that probe is
+    not available, the events recorded around one launch); the other in-run figures stand beside
+    it and bracket it: back to back below, recorded events above."""
+    r = line["roofline"]
+    if "kernel_us_events_around_one_launch" not in r:
+        pytest.skip("line written before the dispatch probe existed")
+    around = r["kernel_us_events_around_one_launch"]
+    by_dispatch = r.get("kernel_us_by_dispatch_events")
+    assert r["kernel_us"] in (by_dispatch, around)
+    assert r["kernel_us"] <= around
+    assert r["kernel_us_back_to_back"] <= around
+    assert r["kernel_us"] * 1e-3 <= line["ms_per_step"]          # a launch is shorter than the step it is part of
+    assert r["frac_of_sustained_instruction_peak"] == pytest.approx(
+        r["achieved"] / r["sustained_instruction_peak"], rel=1e-9)
