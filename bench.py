@@ -874,13 +874,14 @@ def main():
         for _ in range(args.warmup):
             step()
         torch.cuda.synchronize()
+        n = max(args.steps, 200)         # a short --steps would leave this difference of two times to the host's jitter
         t = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(n):
             step()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         check(_lib.lib.slamhip_tune(10, 1), "slamhip_tune")
-        return dt / args.steps
+        return dt / n
     kernel_s_differential = None
     if mfma:
         one = min(timed_steps(1) for _ in range(3))
