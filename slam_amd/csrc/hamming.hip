@@ -464,6 +464,37 @@ __global__ __launch_bounds__(256) void hamming_merge_kernel(const uint2 *__restr
     keep[row] = (od.x >= 0 && od.y >= 0 && (double)od.x < ratio * (double)od.y) ? 1 : 0;
 }
 
+// The same fold with one thread per query row, for a split count known at compile time: the row's
+// S entries are asked for at once (consecutive rows: coalesced 8-byte loads), no LDS, no barrier,
+// a quarter of the workgroups.  Used where S is 2, 4, 8, 16 or 32; on 8192 x 8192 (16 splits)
+// 0.25-0.5 us per call ahead of the kernel above, whose lanes take one entry each.
+template <int S>
+__global__ __launch_bounds__(64) void hamming_merge_rows_kernel(const uint2 *__restrict__ partial, int nq_total,
+                                                                 int32_t *__restrict__ idx2,
+                                                                 int32_t *__restrict__ dist2, double ratio,
+                                                                 uint8_t *__restrict__ keep) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= nq_total) return;
+  uint2 p[S];
+#pragma unroll
+  for (int s = 0; s < S; ++s) p[s] = partial[(size_t)s * nq_total + row];
+  uint32_t b1 = kNoKey, b2 = kNoKey;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    top2_push(b1, b2, p[s].x);
+    top2_push(b1, b2, p[s].y);
+  }
+  int2 oi, od;
+  oi.x = b1 == kNoKey ? -1 : (int32_t)(b1 & kIdxMask);
+  oi.y = b2 == kNoKey ? -1 : (int32_t)(b2 & kIdxMask);
+  od.x = b1 == kNoKey ? -1 : (int32_t)(b1 >> kKeyShift);
+  od.y = b2 == kNoKey ? -1 : (int32_t)(b2 >> kKeyShift);
+  reinterpret_cast<int2 *>(idx2)[row] = oi;
+  reinterpret_cast<int2 *>(dist2)[row] = od;
+  if (keep != nullptr)
+    keep[row] = (od.x >= 0 && od.y >= 0 && (double)od.x < ratio * (double)od.y) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void ratio_test_kernel(const int32_t *__restrict__ dist2, int nq,
                                                          double ratio,
                                                          uint8_t *__restrict__ keep) {
@@ -948,19 +979,36 @@ int run_knn2(const uint8_t *d_query, int nq_total, const uint8_t *d_train, int n
     unfolded->part = part;     // the caller's next kernel folds the splits
     unfolded->splits = p.splits;
   } else if (p.splits > 1) {
-    if (p.splits >= 16 && ev != nullptr && by_dispatch) {
-      // under the dispatch probe the merge launch carries events of its own too (never read): every
-      // dispatch of the probed steps then has a profiling signal, as under a kernel trace
-      static hipEvent_t m0 = nullptr, m1 = nullptr;
-      if (m0 == nullptr && (hipEventCreate(&m0) != hipSuccess || hipEventCreate(&m1) != hipSuccess)) return SLAMHIP_ELAUNCH;
-      hipExtLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
-                            0, st, m0, m1, 0, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
-    } else if (p.splits >= 16)
+    // under the dispatch probe the merge launch carries events of its own too (never read): every
+    // dispatch of the probed steps then has a profiling signal, as under a kernel trace
+    static hipEvent_t m0 = nullptr, m1 = nullptr;
+    const bool signalled = ev != nullptr && by_dispatch;
+    if (signalled && m0 == nullptr && (hipEventCreate(&m0) != hipSuccess || hipEventCreate(&m1) != hipSuccess))
+      return SLAMHIP_ELAUNCH;
+    // one wavefront per workgroup: measured on ten GPUs of one pool, 0.25-0.5 us per 8192 x 8192 call
+    // ahead of the 16-lanes-per-row kernel on every one of them; 256-thread workgroups were another
+    // 0.1-0.2 us ahead on six and 0.1-0.7 us BEHIND that kernel on four
+    constexpr int row_bs = 64;
+    const dim3 row_grid(slamhip_ceil_div(n_out_total, row_bs));
+#define SLAMHIP_MERGE_ROWS(SS)                                                                              \
+  if (signalled)                                                                                            \
+    hipExtLaunchKernelGGL(hamming_merge_rows_kernel<SS>, row_grid, dim3(row_bs), 0, st, m0, m1, 0, part,       \
+                          n_out_total, d_idx2, d_dist2, ratio, d_keep);                                     \
+  else                                                                                                      \
+    hipLaunchKernelGGL(hamming_merge_rows_kernel<SS>, row_grid, dim3(row_bs), 0, st, part, n_out_total, d_idx2, \
+                       d_dist2, ratio, d_keep)
+    if (p.splits == 2) { SLAMHIP_MERGE_ROWS(2); }
+    else if (p.splits == 4) { SLAMHIP_MERGE_ROWS(4); }
+    else if (p.splits == 8) { SLAMHIP_MERGE_ROWS(8); }
+    else if (p.splits == 16) { SLAMHIP_MERGE_ROWS(16); }
+    else if (p.splits == 32) { SLAMHIP_MERGE_ROWS(32); }
+    else if (p.splits >= 16)
       hipLaunchKernelGGL((hamming_merge_kernel<16, 16>), dim3(slamhip_ceil_div(n_out_total, 16)), dim3(256),
                          0, st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
     else
       hipLaunchKernelGGL((hamming_merge_kernel<64, 4>), dim3(slamhip_ceil_div(n_out_total, 64)), dim3(256),
                          0, st, part, n_out_total, p.splits, d_idx2, d_dist2, ratio, d_keep);
+#undef SLAMHIP_MERGE_ROWS
     SLAMHIP_CHECK_LAUNCH();
   } else if (d_keep != nullptr) {
     hipLaunchKernelGGL(ratio_test_kernel, dim3(slamhip_ceil_div(n_out_total, 256)), dim3(256), 0, st,
