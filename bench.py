@@ -887,6 +887,33 @@ def main():
         one = min(timed_steps(1) for _ in range(3))
         two = min(timed_steps(2) for _ in range(3))
         kernel_s_differential = two - one
+    # The same steps issued on two and on three streams in turn (every stream with a bound call,
+    # outputs and workspace of its own): what a caller gets who matches independent pairs and does not
+    # wait for one before it issues the next -- the merge launch of one step and the start of the next
+    # step's top-2 kernel then overlap.  Reported beside `value`, which stays the one-stream rate.
+    def pipelined(n_streams):
+        streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        calls = []
+        for st in streams:
+            with torch.cuda.stream(st):
+                calls.append(kernels.BoundRatioMatch(q, t, RATIO))
+        n = max(args.steps, 1000)
+        t_w = time.perf_counter()
+        while time.perf_counter() - t_w < 0.3:          # new streams: their queues settle over the first milliseconds
+            for i in range(100):
+                calls[i % n_streams]()
+            torch.cuda.synchronize()
+        dt_p = float("inf")
+        for _ in range(3):
+            t_p = time.perf_counter()
+            for i in range(n):
+                calls[i % n_streams]()
+            torch.cuda.synchronize()
+            dt_p = min(dt_p, (time.perf_counter() - t_p) / n)
+        same = all(torch.equal(a, b) for c in calls for a, b in zip(c.out, (idx2, dist2, keep)))
+        return {"streams": n_streams, "us_per_step": dt_p * 1e6, "compares_per_sec": float(NQ) * NT / dt_p,
+                "steps": n, "best_of": 3, "outputs_equal_the_one_stream_run": bool(same)}
+    pipelined_runs = [pipelined(2), pipelined(3)] if dist is None else None
     # (under rocprofv3 the profiler owns the dispatch signals and these events read ~26 us: the
     # events recorded around the launch are then the headline again, and the line says so)
     by_dispatch = bool(mfma and kernel_s_dispatch is not None and 0.0 < kernel_s_dispatch <= kernel_s_single)
@@ -942,6 +969,13 @@ def main():
                              frac_back_to_back=matcher_roofline(mfma, compares, kernel_s, n_launch)["frac"],
                              back_to_back_method=f"{PROBE_REPEAT} identical launches between the two events"),
         }
+        if pipelined_runs is not None:
+            line["pipelined_over_streams"] = {
+                "runs": pipelined_runs,
+                "note": "the same 8192 x 8192 step issued on two / three HIP streams in turn, each with its own "
+                        "bound call, outputs and workspace, timed by the host clock between two device "
+                        "synchronisations: the rate for a caller that matches independent pairs without waiting "
+                        "for one before issuing the next; `value` above is the one-stream rate"}
         # north_star words its target in popcount units (>= 50 % of the popcount-bound roofline):
         # the step's rate against the two popcount ceilings, whichever kernel family ran
         v = line["value"] / world

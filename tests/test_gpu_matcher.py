@@ -488,3 +488,33 @@ def test_bound_call_equals_the_array_native_call():
         i.zero_()
     with pytest.raises(ValueError):
         kernels.BoundRatioMatch(q, t, 0.9, out=(i, d, torch.empty(5, dtype=torch.uint8, device="cuda")))
+
+
+def test_calls_in_flight_on_three_streams_keep_their_results_apart():
+    """Three bound calls on three streams (different pairs, each with its own outputs and
+    workspace), issued in turn without waiting: every call's result is its own pair's, as computed
+    one at a time, while the launches of neighbouring calls overlap on the device."""
+    from slam_amd import kernels
+    rng = np.random.default_rng(21)
+    pairs = [(rng.integers(0, 4, (nq, 61), dtype=np.uint8), rng.integers(0, 4, (nt, 61), dtype=np.uint8))
+             for nq, nt in ((5000, 9000), (8192, 8192), (3000, 4100))]
+    want = [tuple(x.cpu().numpy() for x in kernels.hamming_knn2_ratio(q, t, 0.85)) for q, t in pairs]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in pairs]
+    calls = []
+    for st, (q, t) in zip(streams, pairs):
+        with torch.cuda.stream(st):
+            calls.append(kernels.BoundRatioMatch(q, t, 0.85))
+    torch.cuda.synchronize()
+    for rnd in range(40):
+        for c in calls:
+            c()
+        if rnd == 20:
+            for c in calls:                      # results wiped mid-way: the later calls must write them again
+                for o in c.out:
+                    o.zero_()
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for c, w in zip(calls, want):
+        for got, exp in zip(c.out, w):
+            np.testing.assert_array_equal(got.cpu().numpy(), exp)
