@@ -734,6 +734,9 @@ def main():
     ap.add_argument("--envelope-frames", type=int, default=60,
                     help="frames of the 2000-8000 features/image front-end measurement (0 = skip)")
     ap.add_argument("--no-sweep", action="store_true", help="skip the matcher size sweep")
+    ap.add_argument("--no-pipelined", action="store_true",
+                    help="skip the legs that issue the step on two / three streams (for kernel-trace runs: "
+                         "launches that overlap there would enter the trace's average)")
     ap.add_argument("--section-timeout", type=float, default=300.0,
                     help="seconds the secondary sections (front-end, loop verification) may take together")
     ap.add_argument("--sequence-frames", type=int, default=2761,
@@ -913,7 +916,7 @@ def main():
         same = all(torch.equal(a, b) for c in calls for a, b in zip(c.out, (idx2, dist2, keep)))
         return {"streams": n_streams, "us_per_step": dt_p * 1e6, "compares_per_sec": float(NQ) * NT / dt_p,
                 "steps": n, "best_of": 3, "outputs_equal_the_one_stream_run": bool(same)}
-    pipelined_runs = [pipelined(2), pipelined(3)] if dist is None else None
+    pipelined_runs = [pipelined(2), pipelined(3)] if dist is None and not args.no_pipelined else None
     # (under rocprofv3 the profiler owns the dispatch signals and these events read ~26 us: the
     # events recorded around the launch are then the headline again, and the line says so)
     by_dispatch = bool(mfma and kernel_s_dispatch is not None and 0.0 < kernel_s_dispatch <= kernel_s_single)

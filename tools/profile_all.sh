@@ -14,7 +14,7 @@ stats() {   # stats NAME -- command...
   find $OUT/prof_tmp -name "*kernel_stats.csv" -exec cp {} $OUT/${name}_kernel_stats_${TAG}.csv \;
   rm -rf $OUT/prof_tmp
 }
-MARGS="--no-cpu-baseline --frames 0 --lc-keyframes 0 --sequence-frames 0 --no-sweep"
+MARGS="--no-cpu-baseline --frames 0 --lc-keyframes 0 --sequence-frames 0 --no-sweep --no-pipelined"
 stats bench_matcher8k -- python3 bench.py --steps 400 --warmup 20 $MARGS
 SLAMHIP_MATCHER=popcount stats bench_matcher8k_popcount -- python3 bench.py --steps 400 --warmup 20 $MARGS
 stats frontend500 -- python3 tools/profile_frontend.py 500 1500
